@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF (imported in place from
+/root/reference -- only possible in the build container, never on the GPU box).
+
+For each case the synthetic weights of oracle/weights.py are loaded with
+``load_state_dict(strict=True)`` into the reference's own JETSGenerator
+(models/prompt_tts_modified/jets.py:26), the reference forward
+(jets.py:50-71) is executed exactly like inference_am_vocoder_joint.py:115-129
+does (B = 1, keyword args, alpha = 1.0, torch.no_grad), and inputs, outputs and
+stage taps (forward hooks) are written to a small .npz.
+
+Usage:  python tests/golden/make_golden.py            (re-creates every fixture)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle.weights import EVShapes, synth_inputs, synth_state_dict  # noqa: E402
+
+
+def load_reference():
+    sys.path.insert(0, REF)
+    nb = types.ModuleType("numba")          # modules/alignment.py:9 imports numba; jitted fns are training-only
+    nb.jit = lambda *a, **k: (lambda f: f)
+    sys.modules["numba"] = nb
+
+    class AD(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    def ad(x):
+        return AD({k: ad(v) for k, v in x.items()}) if isinstance(x, dict) else x
+
+    conf = ad(yaml.safe_load(open(os.path.join(REF, "config/joint/config.yaml"))))
+    conf.n_vocab, conf.n_speaker = 502, 2014   # config/joint/config.py:56,60
+    from models.prompt_tts_modified.jets import JETSGenerator
+    return JETSGenerator(conf).eval()
+
+
+def run_reference(gen, sd_np, utt):
+    gen.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    taps = {}
+
+    def hook(name, idx=None):
+        def f(_m, _i, o):
+            o = o[0] if isinstance(o, tuple) else o
+            taps[name] = o.detach().squeeze(0).clone()
+        return f
+
+    hs = []
+    am, voc = gen.am, gen.generator
+    for i in range(4):
+        hs.append(am.encoder.encoders[i].register_forward_hook(hook(f"enc_l{i}")))
+        hs.append(am.decoder.encoders[i].register_forward_hook(hook(f"dec_l{i}")))
+        hs.append(voc.ups[i].register_forward_hook(hook(f"voc_up{i}")))
+    hs.append(am.encoder.register_forward_hook(hook("enc_out")))
+    hs.append(am.decoder.register_forward_hook(hook("dec_out")))
+    hs.append(am.embed_projection1.register_forward_hook(hook("x_proj")))
+    hs.append(am.length_regulator.register_forward_hook(hook("upsampled")))
+    hs.append(voc.conv_pre.register_forward_hook(hook("voc_pre")))
+    # duration_predictor.inference bypasses forward hooks: also run forward() (log domain) below
+    ling = torch.from_numpy(utt["ling"]).long().unsqueeze(0)
+    with torch.no_grad():
+        out = gen(inputs_ling=ling,
+                  inputs_style_embedding=torch.from_numpy(utt["style"]).unsqueeze(0),
+                  input_lengths=torch.tensor([ling.shape[1]]),
+                  inputs_content_embedding=torch.from_numpy(utt["content"]).unsqueeze(0),
+                  inputs_speaker=torch.tensor([utt["speaker"]]),
+                  alpha=1.0)
+        log_d = am.duration_predictor(taps["x_proj"].unsqueeze(0), None).squeeze(0)
+    for h in hs:
+        h.remove()
+    res = dict(
+        dur=out["log_duration_predictions"].squeeze(0).numpy().astype(np.int64),
+        log_dur=log_d.numpy(),
+        pitch=out["pitch_predictions"].reshape(-1).numpy(),
+        energy=out["energy_predictions"].reshape(-1).numpy(),
+        mel=out["dec_outputs"].squeeze(0).numpy(),
+        wav=out["wav_predictions"].reshape(-1).numpy(),
+    )
+    res["mel_len"] = np.int64(res["mel"].shape[0])
+    for k, v in taps.items():
+        res["tap_" + k] = v.numpy()
+    return res
+
+
+CASES = {
+    # name: (weight seed, dur_mode, input seed, lengths, speakers)
+    "tiny_parity": (0, "parity", 11, [12], [5]),
+    "n40_stress": (0, "stress", 12, [40], [1999]),
+    "n33_bench": (0, "bench", 13, [33], [0]),
+}
+
+
+def real_line_case():
+    """data/inference/text:1 (speaker 8051, prompt 'Happy'): real phoneme distribution."""
+    toks = [l.rstrip("\n") for l in open(os.path.join(REF, "data/youdao/text/tokenlist"))]
+    tok2id = {t: i for i, t in enumerate(toks)}
+    spks = [l.rstrip("\n") for l in open(os.path.join(REF, "data/youdao/text/speaker2"))]
+    spk2id = {t: i for i, t in enumerate(spks)}
+    line = open(os.path.join(REF, "data/inference/text")).readline().strip().split("|")
+    ling = np.array([tok2id[p] for p in line[2].split()], np.int64)
+    u = synth_inputs(14, [len(ling)])[0]
+    u["ling"], u["speaker"] = ling, spk2id[line[0]]
+    return u, line
+
+
+def subsample_taps(res, limit=12000):
+    """Keep fixtures small: big taps are stored strided along their time axis; the axis and
+    stride are encoded in the key (``tap_<name>__ax<axis>_s<stride>``)."""
+    out = {}
+    for k, v in res.items():
+        if k.startswith("tap_") and v.size > limit:
+            ax = 1 if k.startswith("tap_voc_") else 0
+            stride = int(np.ceil(v.size / limit))
+            sl = [slice(None)] * v.ndim
+            sl[ax] = slice(None, None, stride)
+            out[f"{k}__ax{ax}_s{stride}"] = np.ascontiguousarray(v[tuple(sl)])
+        else:
+            out[k] = v
+    return out
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen = load_reference()
+    shapes = EVShapes()
+    sds = {}
+    for name, (wseed, mode, iseed, lengths, speakers) in CASES.items():
+        if (wseed, mode) not in sds:
+            sds[(wseed, mode)] = synth_state_dict(wseed, mode, shapes)
+        utt = synth_inputs(iseed, lengths, speakers, shapes)[0]
+        res = run_reference(gen, sds[(wseed, mode)], utt)
+        res = subsample_taps(res)
+        res.update(in_ling=utt["ling"], in_speaker=np.int64(utt["speaker"]), in_style=utt["style"],
+                   in_content=utt["content"], weight_seed=np.int64(wseed), dur_mode=np.array(mode))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+        print(name, "N", lengths[0], "T", int(res["mel_len"]), "dur[min,max]", res["dur"].min(), res["dur"].max(),
+              "wav rms %.4f" % float(np.sqrt((res["wav"] ** 2).mean())))
+    utt, line = real_line_case()
+    if (0, "parity") not in sds:
+        sds[(0, "parity")] = synth_state_dict(0, "parity", shapes)
+    res = subsample_taps(run_reference(gen, sds[(0, "parity")], utt))
+    res.update(in_ling=utt["ling"], in_speaker=np.int64(utt["speaker"]), in_style=utt["style"],
+               in_content=utt["content"], weight_seed=np.int64(0), dur_mode=np.array("parity"),
+               text_line=np.array("|".join(line)))
+    np.savez_compressed(os.path.join(HERE, "real_line1.npz"), **res)
+    print("real_line1 N", len(utt["ling"]), "T", int(res["mel_len"]))
+
+
+if __name__ == "__main__":
+    main()
