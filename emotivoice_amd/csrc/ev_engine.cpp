@@ -1,0 +1,1004 @@
+// libevhip.so host side: handle, packed-weight table, workspace arena, row layouts, forward
+// orchestration and the C ABI declared in include/evhip.h.
+//
+// Data layout in HBM: every activation is channels-last [rows][channels].
+// Rows of a batch are laid out with zero gaps between utterances:
+//     [G gap rows][utt 0 rows][G gap rows][utt 1 rows] ... [G gap rows][pad to a multiple of 256]
+// G = 4 at token rate and at mel-frame rate; the vocoder's upsampled stages inherit the frame
+// layout scaled by the cumulative upsampling factor (gap 32 / 256 / 512 / 1024 rows >= the largest
+// conv halo of that stage, 25 rows).  Every kernel writes exact zeros into invalid rows, so a conv
+// that reads across an utterance edge sees the zero padding the reference's per-utterance (B = 1)
+// Conv1d(padding=...) provides, and no conv ever needs a per-row bounds test.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/evhip.h"
+#include "../../include/evhip_ops.h"
+#include "ev_kernels.h"
+
+using namespace ev;
+
+namespace {
+
+constexpr int GAP = 4;            // gap rows between utterances (token and frame rate)
+constexpr int ROW_ALIGN = 256;    // row counts are padded to the largest GEMM M tile
+constexpr int PAD_ROWS = 64;      // readable slack rows before / after every activation buffer
+constexpr int MEL_PAD = 96;       // n_mels padded to a multiple of 32 (MFMA K granularity)
+
+thread_local std::string g_create_error;
+
+struct WeightEntry { int dtype; int ndim; uint64_t dims[4]; const char* ptr; uint64_t nbytes; };
+
+struct Buf {              // activation buffer with PAD_ROWS of slack on both sides
+    char* base = nullptr; // allocation start
+    char* p = nullptr;    // logical row 0
+    size_t bytes = 0;
+};
+
+struct Tap { const void* ptr; int dtype; int ld; int C; int level; /* 0 token, 1 frame, 2+s vocoder stage s */ int shift; };
+
+struct KStat { std::string name; int launches = 0; float ms = 0; double flops = 0, bytes = 0; };
+struct PendingEvt { hipEvent_t a, b; int stat; };
+
+}  // namespace
+
+struct ev_handle {
+    ev_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    // weights
+    char* wblob = nullptr; bool wblob_owned = false; size_t wbytes = 0;
+    std::map<std::string, WeightEntry> wt;
+    std::map<std::string, float> scalar_cache;   // host copies of 1-element tensors (biases of the Linear(C,1) heads, PE alphas)
+    // arena
+    char* arena[2] = {nullptr, nullptr}; size_t arena_bytes[2] = {0, 0};   // [0] token-rate phase, [1] frame-rate phase + vocoder
+    char* pinned = nullptr; size_t pinned_bytes = 0;
+    // persistent outputs (host side)
+    std::vector<int32_t> mel_lens; std::vector<int64_t> mel_offs;
+    std::vector<int64_t> forced_dur;
+    // layout of the last call
+    int B = 0, total_tokens = 0; int64_t total_frames = 0;
+    int Rt = 0, Rf = 0;
+    std::vector<int32_t> tok_off, tok_len, frm_off;
+    std::map<std::string, Tap> taps;
+    const int64_t* last_dur = nullptr; const int32_t* last_mel_len_dev = nullptr;
+    // device maps (inside the arena)
+    int32_t *d_tok_seq = nullptr, *d_tok_pos = nullptr, *d_tok_off = nullptr, *d_tok_len = nullptr, *d_cu = nullptr;
+    uint8_t* d_tok_valid = nullptr;
+    int32_t *d_frm_seq = nullptr, *d_frm_pos = nullptr, *d_frm_off = nullptr, *d_mel_len = nullptr;
+    uint8_t* d_frm_valid = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<KStat> stats; std::map<std::string, int> stat_idx;
+    std::vector<PendingEvt> pending; std::vector<hipEvent_t> evt_pool; size_t evt_next = 0;
+    std::map<std::string, float> timings;
+    std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> region_evt;
+};
+
+namespace {
+
+int fail(ev_handle* h, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return -1;
+}
+
+#define HIPCHK(h, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+// ---------------------------------------------------------------- weights
+// Blob layout (emotivoice_amd/packer.py): "EVW1\0\0\0\0" | u32 count | u32 reserved |
+// count x { char name[64]; u32 dtype(0 f16,1 f32,2 i32,3 i64); u32 ndim; u64 dims[4]; u64 offset; u64 nbytes } | data (256-B aligned)
+struct BlobEntry { char name[64]; uint32_t dtype, ndim; uint64_t dims[4]; uint64_t offset, nbytes; };
+
+int parse_blob(ev_handle* h, const char* host_hdr, size_t nbytes) {
+    if (nbytes < 16 || memcmp(host_hdr, "EVW1", 4) != 0) return fail(h, "weight blob: bad magic");
+    uint32_t count;
+    memcpy(&count, host_hdr + 8, 4);
+    if (16 + (size_t)count * sizeof(BlobEntry) > nbytes) return fail(h, "weight blob: truncated table");
+    h->wt.clear();
+    h->scalar_cache.clear();
+    for (uint32_t i = 0; i < count; ++i) {
+        BlobEntry e;
+        memcpy(&e, host_hdr + 16 + (size_t)i * sizeof(BlobEntry), sizeof e);
+        e.name[63] = 0;
+        if (e.offset + e.nbytes > nbytes) return fail(h, "weight blob: tensor %s out of range", e.name);
+        WeightEntry w;
+        w.dtype = (int)e.dtype; w.ndim = (int)e.ndim; memcpy(w.dims, e.dims, sizeof w.dims);
+        w.ptr = h->wblob + e.offset; w.nbytes = e.nbytes;
+        h->wt[e.name] = w;
+    }
+    return 0;
+}
+
+const WeightEntry* W(ev_handle* h, const std::string& name) {
+    auto it = h->wt.find(name);
+    if (it == h->wt.end()) { h->err = "missing packed weight: " + name; return nullptr; }
+    return &it->second;
+}
+#define WPTR(var, type, name)                                   \
+    const type* var;                                            \
+    {                                                           \
+        const WeightEntry* _w = W(h, name);                     \
+        if (!_w) return -1;                                     \
+        var = reinterpret_cast<const type*>(_w->ptr);           \
+    }
+
+int get_scalar(ev_handle* h, const std::string& name, float* v) {
+    auto it = h->scalar_cache.find(name);
+    if (it == h->scalar_cache.end()) {
+        const WeightEntry* w = W(h, name);
+        if (!w) return -1;
+        float x;
+        HIPCHK(h, hipMemcpy(&x, w->ptr, 4, hipMemcpyDeviceToHost));
+        it = h->scalar_cache.emplace(name, x).first;
+    }
+    *v = it->second;
+    return 0;
+}
+
+// ---------------------------------------------------------------- arena
+int arena_reserve(ev_handle* h, int idx, size_t bytes) {
+    if (bytes <= h->arena_bytes[idx]) return 0;
+    if (h->arena[idx]) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->arena[idx])); h->arena[idx] = nullptr; h->arena_bytes[idx] = 0; }
+    bytes = align_up(bytes + bytes / 8, 1 << 20);
+    HIPCHK(h, hipMalloc((void**)&h->arena[idx], bytes));
+    HIPCHK(h, hipMemsetAsync(h->arena[idx], 0, bytes, h->stream));
+    h->arena_bytes[idx] = bytes;
+    return 0;
+}
+struct ArenaPlan {   // two-pass: the dry pass measures, the second pass hands out pointers
+    ev_handle* h; int idx; bool dry; size_t off = 0;
+    char* take(size_t bytes) {
+        off = align_up(off, 256);
+        char* p = dry ? nullptr : h->arena[idx] + off;
+        off += bytes;
+        return p;
+    }
+    Buf rows(size_t rows, size_t ld, size_t es) {
+        Buf b;
+        const size_t pad = (size_t)PAD_ROWS * ld * es;
+        b.bytes = rows * ld * es;
+        b.base = take(pad + b.bytes + pad);
+        b.p = dry ? nullptr : b.base + pad;
+        return b;
+    }
+    template <typename T> T* arr(size_t n) { return reinterpret_cast<T*>(take(n * sizeof(T))); }
+};
+
+int pinned_reserve(ev_handle* h, size_t bytes) {
+    if (bytes <= h->pinned_bytes) return 0;
+    if (h->pinned) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipHostFree(h->pinned)); h->pinned = nullptr; }
+    bytes = align_up(bytes * 2, 1 << 16);
+    HIPCHK(h, hipHostMalloc((void**)&h->pinned, bytes, hipHostMallocDefault));
+    h->pinned_bytes = bytes;
+    return 0;
+}
+
+// ---------------------------------------------------------------- profiling helpers
+int stat_id(ev_handle* h, const char* name) {
+    auto it = h->stat_idx.find(name);
+    if (it != h->stat_idx.end()) return it->second;
+    KStat s; s.name = name;
+    h->stats.push_back(s);
+    h->stat_idx[name] = (int)h->stats.size() - 1;
+    return (int)h->stats.size() - 1;
+}
+hipEvent_t get_evt(ev_handle* h) {
+    if (h->evt_next == h->evt_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); h->evt_pool.push_back(e); }
+    return h->evt_pool[h->evt_next++];
+}
+struct KScope {   // wraps one kernel launch with events when profiling is on
+    ev_handle* h; int sid = -1; hipEvent_t a{}, b{};
+    KScope(ev_handle* h_, const char* name, double flops, double bytes) : h(h_) {
+        if (!h->profiling) return;
+        sid = stat_id(h, name);
+        h->stats[sid].launches++; h->stats[sid].flops += flops; h->stats[sid].bytes += bytes;
+        a = get_evt(h); b = get_evt(h);
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~KScope() {
+        if (sid < 0) return;
+        (void)hipEventRecord(b, h->stream);
+        h->pending.push_back({a, b, sid});
+    }
+};
+void region_begin(ev_handle* h, const char* name) {
+    if (!h->profiling) return;
+    auto& pr = h->region_evt[name];
+    if (!pr.first) { (void)hipEventCreate(&pr.first); (void)hipEventCreate(&pr.second); }
+    (void)hipEventRecord(pr.first, h->stream);
+}
+void region_end(ev_handle* h, const char* name) {
+    if (!h->profiling) return;
+    (void)hipEventRecord(h->region_evt[name].second, h->stream);
+}
+void profiling_reset(ev_handle* h) {
+    h->stats.clear(); h->stat_idx.clear(); h->pending.clear(); h->evt_next = 0; h->timings.clear();
+}
+void profiling_collect(ev_handle* h) {
+    if (!h->profiling) return;
+    for (auto& p : h->pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b); h->stats[p.stat].ms += ms; }
+    h->pending.clear();
+    for (auto& kv : h->region_evt) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, kv.second.first, kv.second.second) == hipSuccess) h->timings[kv.first] = ms;
+    }
+}
+
+// ---------------------------------------------------------------- launch wrappers with precondition checks
+int check_gemm(ev_handle* h, const ConvGemmParams& p) {
+    const int es = p.dtype == DT_F16 ? 2 : 4;
+    if (p.M % ROW_ALIGN) return fail(h, "gemm: M=%d not a multiple of %d", p.M, ROW_ALIGN);
+    if (p.N % 32) return fail(h, "gemm: N=%d not a multiple of 32", p.N);
+    if ((p.K * es) % 64) return fail(h, "gemm: K=%d not a multiple of %d", p.K, 64 / es);
+    if ((p.taps - 1) * p.dil > 64) return fail(h, "gemm: conv span %d > 64", (p.taps - 1) * p.dil);
+    if (p.center * p.dil > PAD_ROWS || (p.taps - 1 - p.center) * p.dil > PAD_ROWS) return fail(h, "gemm: halo exceeds buffer slack");
+    if ((p.lda * es) % 16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return fail(h, "gemm: unaligned operand");
+    if (!p.out16 && !p.out32) return fail(h, "gemm: no output");
+    return 0;
+}
+int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_rows) {
+    if (check_gemm(h, p)) return -1;
+    const int es = p.dtype == DT_F16 ? 2 : 4;
+    const double flops = 2.0 * valid_rows * p.N * (double)p.K * p.taps;
+    double bytes = valid_rows * ((double)p.K * es + (double)p.N * (p.out16 ? 2 : 0) + (double)p.N * (p.out32 ? 4 : 0)) +
+                   (double)p.N * p.K * p.taps * es;
+    KScope ks(h, name, flops, bytes);
+    launch_conv_gemm(p, h->stream);
+    return 0;
+}
+ConvGemmParams gemm_defaults() {
+    ConvGemmParams p;
+    memset(&p, 0, sizeof p);
+    p.taps = 1; p.dil = 1; p.center = 0; p.out_scale = 1.0f;
+    return p;
+}
+
+struct RowCtx {     // one row layout (token rate or frame rate)
+    int R; const uint8_t* valid; const int32_t* row_seq; const int32_t* seq_off; const int32_t* seq_len; int B; int max_len;
+    double n_valid;
+};
+
+// Encoder / decoder stack (reference modules/encoder.py:316-324, layer :154-200).  x (fp32 residual stream,
+// [R][C]) is updated in place; y receives after_norm(x) in `prec` dtype (and y32_tap in fp32 if given).
+int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx& rc, Buf& x, Buf& hbuf, Buf& qkv, Buf& ctx, Buf& ffn,
+              Buf& y, float* y32_tap, std::vector<Buf>* layer_taps) {
+    const int C = h->cfg.hidden, F = 4 * C, kf = h->cfg.ffn_kernel;
+    const char* wsuf = prec == DT_F16 ? "w16" : "w32";
+    const std::string sp(pre);
+    const std::string kn = std::string(pre) + (prec == DT_F16 ? "_f16" : "_f32");
+    for (int i = 0; i < layers; ++i) {
+        const std::string lp = sp + "." + std::to_string(i);
+        WPTR(g1, float, lp + ".ln1.g"); WPTR(b1, float, lp + ".ln1.b");
+        WPTR(g2, float, lp + ".ln2.g"); WPTR(b2, float, lp + ".ln2.b");
+        WPTR(wqkv, char, lp + ".qkv." + wsuf); WPTR(bqkv, float, lp + ".qkv.b");
+        WPTR(wout, char, lp + ".out." + wsuf); WPTR(bout, float, lp + ".out.b");
+        WPTR(wf1, char, lp + ".ffn1." + wsuf); WPTR(bf1, float, lp + ".ffn1.b");
+        WPTR(wf2, char, lp + ".ffn2." + wsuf); WPTR(bf2, float, lp + ".ffn2.b");
+        LayerNormParams ln{};
+        ln.x = (const float*)x.p; ln.ldx = C; ln.rows = rc.R; ln.C = C; ln.gamma = g1; ln.beta = b1; ln.eps = 1e-12f;
+        ln.row_valid = rc.valid; ln.ldo = C;
+        if (prec == DT_F16) ln.out16 = hbuf.p; else ln.out32 = (float*)hbuf.p;
+        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
+        ConvGemmParams p = gemm_defaults();
+        p.dtype = prec; p.A = hbuf.p; p.lda = C; p.W = wqkv; p.bias = bqkv; p.M = rc.R; p.N = 3 * C; p.K = C;
+        p.row_valid = rc.valid; p.ldo = 3 * C;
+        if (prec == DT_F16) p.out16 = qkv.p; else p.out32 = (float*)qkv.p;
+        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        AttnParams ap{};
+        ap.qkv = qkv.p; ap.dtype = prec; ap.ld = 3 * C; ap.C = C; ap.heads = h->cfg.heads; ap.seq_off = rc.seq_off;
+        ap.seq_len = rc.seq_len; ap.B = rc.B; ap.max_len = rc.max_len; ap.out = ctx.p; ap.ldo = C;
+        { KScope ks(h, (kn + "_attention").c_str(), 0, 0); launch_attention(ap, h->stream); }
+        p = gemm_defaults();
+        p.dtype = prec; p.A = ctx.p; p.lda = C; p.W = wout; p.bias = bout; p.M = rc.R; p.N = C; p.K = C;
+        p.row_valid = rc.valid; p.res = x.p; p.res_dtype = DT_F32; p.ldres = C; p.out32 = (float*)x.p; p.ldo = C;
+        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        ln.gamma = g2; ln.beta = b2;
+        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
+        p = gemm_defaults();
+        p.dtype = prec; p.A = hbuf.p; p.lda = C; p.W = wf1; p.bias = bf1; p.M = rc.R; p.N = F; p.K = C; p.taps = kf; p.center = (kf - 1) / 2;
+        p.row_valid = rc.valid; p.act = ACT_GELU; p.ldo = F;
+        if (prec == DT_F16) p.out16 = ffn.p; else p.out32 = (float*)ffn.p;
+        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        p = gemm_defaults();
+        p.dtype = prec; p.A = ffn.p; p.lda = F; p.W = wf2; p.bias = bf2; p.M = rc.R; p.N = C; p.K = F; p.taps = kf; p.center = (kf - 1) / 2;
+        p.row_valid = rc.valid; p.res = x.p; p.res_dtype = DT_F32; p.ldres = C; p.out32 = (float*)x.p; p.ldo = C;
+        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        if (layer_taps) HIPCHK(h, hipMemcpyAsync((*layer_taps)[i].p, x.p, x.bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    WPTR(ga, float, sp + ".after.g"); WPTR(ba, float, sp + ".after.b");
+    LayerNormParams ln{};
+    ln.x = (const float*)x.p; ln.ldx = C; ln.rows = rc.R; ln.C = C; ln.gamma = ga; ln.beta = ba; ln.eps = 1e-12f;
+    ln.row_valid = rc.valid; ln.ldo = C;
+    if (prec == DT_F16) { ln.out16 = y.p; ln.out32 = y32_tap; } else { ln.out32 = (float*)y.p; }
+    { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
+    return 0;
+}
+
+// Variance / duration predictor (reference modules/variance.py:36-56, 101-124): n x [conv k3 -> ReLU -> LN] -> Linear(C,1)
+int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, const Buf& xin, Buf& t1, Buf& t2, float* out_rows) {
+    const int C = h->cfg.hidden, k = h->cfg.var_kernel;
+    const std::string sp(name);
+    const void* cur = xin.p;
+    for (int i = 0; i < layers; ++i) {
+        const std::string lp = sp + "." + std::to_string(i);
+        WPTR(w, char, lp + ".conv.w32"); WPTR(b, float, lp + ".conv.b");
+        WPTR(g, float, lp + ".ln.g"); WPTR(be, float, lp + ".ln.b");
+        ConvGemmParams p = gemm_defaults();
+        p.dtype = DT_F32; p.A = cur; p.lda = C; p.W = w; p.bias = b; p.M = rc.R; p.N = C; p.K = C; p.taps = k; p.center = (k - 1) / 2;
+        p.row_valid = rc.valid; p.act = ACT_RELU; p.out32 = (float*)t1.p; p.ldo = C;
+        if (gemm(h, "variance_f32_gemm", p, rc.n_valid)) return -1;
+        LayerNormParams ln{};
+        ln.x = (const float*)t1.p; ln.ldx = C; ln.rows = rc.R; ln.C = C; ln.gamma = g; ln.beta = be; ln.eps = 1e-12f;
+        ln.row_valid = rc.valid; ln.ldo = C;
+        if (i + 1 < layers) {
+            ln.out32 = (float*)t2.p;
+        } else {
+            WPTR(lw, float, sp + ".lin.w");
+            float lbv;
+            if (get_scalar(h, sp + ".lin.b", &lbv)) return -1;
+            ln.dot_w = lw; ln.dot_b = lbv; ln.dot_out = out_rows;
+        }
+        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 8.0); launch_layernorm(ln, h->stream); }
+        cur = t2.p;
+    }
+    return 0;
+}
+
+struct VocBufs { Buf pre, xu[4], tmp, rba, rbb, nxt[4], mrf32, wavrows; Buf mrf_tap[4]; Buf pre_tap; };
+
+// HiFi-GAN generator (reference models/hifigan/models.py:115-131) on channels-last fp16 rows.
+int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs& vb, bool keep) {
+    const ev_config& c = h->cfg;
+    WPTR(wpre, char, "voc.pre.w16"); WPTR(bpre, float, "voc.pre.b");
+    ConvGemmParams p = gemm_defaults();
+    p.dtype = DT_F16; p.A = mel16.p; p.lda = MEL_PAD; p.W = wpre; p.bias = bpre; p.M = Rf; p.N = c.up_init_ch; p.K = MEL_PAD;
+    p.taps = 7; p.center = 3; p.row_valid = h->d_frm_valid; p.valid_shift = 0;
+    p.post_lrelu = 1; p.post_slope = 0.1f;      // leaky_relu(0.1) of models.py:118 fused into the producer
+    p.out16 = vb.pre.p; p.ldo = c.up_init_ch;
+    if (keep) { p.out32 = (float*)vb.pre_tap.p; p.out32_before_post = 1; }
+    if (gemm(h, "voc_conv_gemm_f16", p, n_frames)) return -1;
+    const void* prev = vb.pre.p;
+    int ch = c.up_init_ch, U = 1;
+    for (int i = 0; i < c.n_up; ++i) {
+        const int s = c.up_rates[i], cout = ch / 2;
+        const int rows_in = Rf * U, rows_out = rows_in * s;
+        const double valid_in = n_frames * U, valid_out = valid_in * s;
+        const std::string up = "voc.up" + std::to_string(i);
+        WPTR(wu, char, up + ".w16"); WPTR(bu, float, up + ".b");
+        // ConvTranspose1d(k = 2s, pad = s/2) == 3-tap conv with N = s * C_out, viewed as [rows_in*s][C_out] (models.py:119)
+        p = gemm_defaults();
+        p.dtype = DT_F16; p.A = prev; p.lda = ch; p.W = wu; p.bias = bu; p.M = rows_in; p.N = s * cout; p.K = ch; p.taps = 3; p.center = 1;
+        p.row_valid = h->d_frm_valid; p.valid_shift = ilog2(U); p.out16 = vb.xu[i].p; p.ldo = s * cout;
+        if (gemm(h, "voc_conv_gemm_f16", p, valid_in)) return -1;
+        U *= s;
+        const int shift = ilog2(U);
+        const bool last_stage = (i == c.n_up - 1);
+        for (int j = 0; j < c.n_rb; ++j) {
+            const int k = c.rb_kernels[j];
+            const std::string rb = "voc.rb" + std::to_string(i * c.n_rb + j);
+            const void* xcur = vb.xu[i].p;
+            for (int d = 0; d < c.n_rb_dils; ++d) {
+                const int dil = c.rb_dils[j][d];
+                WPTR(w1, char, rb + ".c1." + std::to_string(d) + ".w16"); WPTR(b1, float, rb + ".c1." + std::to_string(d) + ".b");
+                WPTR(w2, char, rb + ".c2." + std::to_string(d) + ".w16"); WPTR(b2, float, rb + ".c2." + std::to_string(d) + ".b");
+                // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
+                p = gemm_defaults();
+                p.dtype = DT_F16; p.A = xcur; p.lda = cout; p.W = w1; p.bias = b1; p.M = rows_out; p.N = cout; p.K = cout;
+                p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
+                p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.out16 = vb.tmp.p; p.ldo = cout;
+                if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
+                // x = c2(xt) + x  (models.py:54-56)
+                p = gemm_defaults();
+                p.dtype = DT_F16; p.A = vb.tmp.p; p.lda = cout; p.W = w2; p.bias = b2; p.M = rows_out; p.N = cout; p.K = cout;
+                p.taps = k; p.dil = 1; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
+                p.res = xcur; p.res_dtype = DT_F16; p.ldres = cout; p.ldo = cout;
+                if (d + 1 < c.n_rb_dils) {
+                    void* dst = (d % 2 == 0) ? vb.rba.p : vb.rbb.p;
+                    p.out16 = dst;
+                    xcur = dst;
+                } else {
+                    // MRF: xs += resblock(x); x = xs / num_kernels (models.py:121-126), then the next leaky_relu
+                    p.out_scale = 1.0f / (float)c.n_rb;
+                    if (j > 0) { p.acc32 = (const float*)vb.mrf32.p; p.ldacc = cout; }
+                    if (j + 1 < c.n_rb) {
+                        p.out32 = (float*)vb.mrf32.p;
+                    } else {
+                        p.post_lrelu = 1; p.post_slope = last_stage ? 0.01f : 0.1f;   // models.py:118 / :127
+                        p.out16 = vb.nxt[i].p;
+                        if (keep) { p.out32 = (float*)vb.mrf_tap[i].p; p.out32_before_post = 1; }
+                    }
+                }
+                if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
+            }
+        }
+        prev = vb.nxt[i].p;
+        ch = cout;
+    }
+    WPTR(wpost, float, "voc.post.w");
+    float bpv;
+    if (get_scalar(h, "voc.post.b", &bpv)) return -1;
+    {
+        KScope ks(h, "voc_conv_post", 2.0 * n_frames * U * ch * 7, n_frames * U * (ch * 2.0 + 4.0));
+        launch_conv_post(prev, ch, wpost, bpv, 7, h->d_frm_valid, ilog2(U), (float*)vb.wavrows.p, Rf * U, ch, h->stream);
+    }
+    return 0;
+}
+
+int total_up(const ev_config& c) { int u = 1; for (int i = 0; i < c.n_up; ++i) u *= c.up_rates[i]; return u; }
+
+void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs& vb) {
+    vb.pre = ap.rows(Rf, c.up_init_ch, 2);
+    if (keep) vb.pre_tap = ap.rows(Rf, c.up_init_ch, 4);
+    int ch = c.up_init_ch, U = 1;
+    size_t max_elems = 0;
+    for (int i = 0; i < c.n_up; ++i) {
+        U *= c.up_rates[i]; ch /= 2;
+        max_elems = std::max(max_elems, (size_t)Rf * U * ch);
+    }
+    // stage buffers are re-used across stages unless taps are kept
+    ch = c.up_init_ch; U = 1;
+    Buf shared_xu{}, shared_nxt[2];
+    for (int i = 0; i < c.n_up; ++i) {
+        U *= c.up_rates[i]; ch /= 2;
+        if (keep) {
+            vb.xu[i] = ap.rows((size_t)Rf * U, ch, 2);
+            vb.nxt[i] = ap.rows((size_t)Rf * U, ch, 2);
+            vb.mrf_tap[i] = ap.rows((size_t)Rf * U, ch, 4);
+        }
+    }
+    if (!keep) {
+        // row pitch differs per stage, so size by elements with the largest pad (C = 256 rows of slack)
+        auto mk = [&]() { Buf b; const size_t pad = (size_t)PAD_ROWS * 512 * 2; b.bytes = max_elems * 2; b.base = ap.take(pad + b.bytes + pad); b.p = ap.dry ? nullptr : b.base + pad; return b; };
+        shared_xu = mk(); shared_nxt[0] = mk(); shared_nxt[1] = mk();
+        for (int i = 0; i < c.n_up; ++i) { vb.xu[i] = shared_xu; vb.nxt[i] = shared_nxt[i & 1]; }
+    }
+    auto mk2 = [&](size_t es) { Buf b; const size_t pad = (size_t)PAD_ROWS * 512 * es; b.bytes = max_elems * es; b.base = ap.take(pad + b.bytes + pad); b.p = ap.dry ? nullptr : b.base + pad; return b; };
+    vb.tmp = mk2(2); vb.rba = mk2(2); vb.rbb = mk2(2); vb.mrf32 = mk2(4);
+    vb.wavrows = ap.rows((size_t)Rf * total_up(c), 1, 4);
+}
+
+// frame layout from mel lengths (host) -> device maps; returns Rf
+int build_frame_layout(ev_handle* h, ArenaPlan& ap, bool dry, int B) {
+    int64_t rows = GAP;
+    h->frm_off.resize(B);
+    h->mel_offs.assign(B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        h->frm_off[b] = (int32_t)rows;
+        rows += h->mel_lens[b] + GAP;
+        h->mel_offs[b + 1] = h->mel_offs[b] + h->mel_lens[b];
+    }
+    h->total_frames = h->mel_offs[B];
+    const int Rf = (int)align_up((size_t)rows, ROW_ALIGN);
+    h->d_frm_seq = ap.arr<int32_t>(Rf); h->d_frm_pos = ap.arr<int32_t>(Rf); h->d_frm_valid = ap.arr<uint8_t>(Rf);
+    h->d_frm_off = ap.arr<int32_t>(B);
+    if (!dry) {
+        char* st = h->pinned;   // caller reserved >= Rf*9 + B*4 bytes
+        int32_t* seq = (int32_t*)st; int32_t* pos = seq + Rf; int32_t* off = pos + Rf; uint8_t* valid = (uint8_t*)(off + B);
+        for (int r = 0; r < Rf; ++r) { seq[r] = -1; pos[r] = 0; valid[r] = 0; }
+        for (int b = 0; b < B; ++b) {
+            off[b] = h->frm_off[b];
+            for (int t = 0; t < h->mel_lens[b]; ++t) { const int r = h->frm_off[b] + t; seq[r] = b; pos[r] = t; valid[r] = 1; }
+        }
+        (void)hipMemcpyAsync(h->d_frm_seq, seq, (size_t)Rf * 4, hipMemcpyHostToDevice, h->stream);
+        (void)hipMemcpyAsync(h->d_frm_pos, pos, (size_t)Rf * 4, hipMemcpyHostToDevice, h->stream);
+        (void)hipMemcpyAsync(h->d_frm_off, off, (size_t)B * 4, hipMemcpyHostToDevice, h->stream);
+        (void)hipMemcpyAsync(h->d_frm_valid, valid, (size_t)Rf, hipMemcpyHostToDevice, h->stream);
+        (void)hipStreamSynchronize(h->stream);   // the pinned staging area is re-used
+    }
+    return Rf;
+}
+
+// gather per-utterance valid rows of a row-layout buffer into a packed fp32 device buffer
+int pack_level(ev_handle* h, const void* src, int dtype, int ld, int C, int level_shift, bool token_level, float* dst, int64_t* d_scratch3B) {
+    const int B = h->B;
+    std::vector<int64_t> host(3 * (size_t)B);
+    int64_t max_rows = 0, out = 0;
+    std::vector<int32_t> rows32(B);
+    for (int b = 0; b < B; ++b) {
+        const int64_t n = token_level ? h->tok_len[b] : ((int64_t)h->mel_lens[b] << level_shift);
+        host[b] = token_level ? h->tok_off[b] : ((int64_t)h->frm_off[b] << level_shift);
+        host[B + b] = out;
+        rows32[b] = (int32_t)n;
+        out += n; max_rows = std::max(max_rows, n);
+    }
+    int64_t* d_row_off = d_scratch3B; int64_t* d_out_off = d_scratch3B + B; int32_t* d_rows = (int32_t*)(d_scratch3B + 2 * B);
+    HIPCHK(h, hipMemcpyAsync(d_row_off, host.data(), (size_t)2 * B * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_rows, rows32.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    launch_pack_rows(src, dtype, ld, C, d_row_off, d_out_off, d_rows, B, max_rows, dst, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
+    return 0;
+}
+
+void add_tap(ev_handle* h, const char* name, const void* ptr, int dtype, int ld, int C, int level, int shift) {
+    Tap t{ptr, dtype, ld, C, level, shift};
+    h->taps[name] = t;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+
+extern "C" {
+
+void ev_default_config(ev_config* c) {
+    memset(c, 0, sizeof *c);
+    c->abi_version = EV_ABI_VERSION;
+    c->n_vocab = 502; c->n_speaker = 2014; c->n_mels = 80; c->hidden = 384; c->heads = 8; c->enc_layers = 4; c->dec_layers = 4;
+    c->ffn_kernel = 3; c->bert_dim = 768; c->dur_layers = 2; c->pitch_layers = 3; c->energy_layers = 2; c->var_kernel = 3;
+    c->var_embed_kernel = 9; c->n_up = 4;
+    const int ur[4] = {8, 8, 2, 2}, uk[4] = {16, 16, 4, 4}, rk[3] = {3, 7, 11}, rd[3] = {1, 3, 5};
+    for (int i = 0; i < 4; ++i) { c->up_rates[i] = ur[i]; c->up_kernels[i] = uk[i]; }
+    c->up_init_ch = 512; c->n_rb = 3; c->n_rb_dils = 3;
+    for (int j = 0; j < 3; ++j) { c->rb_kernels[j] = rk[j]; for (int d = 0; d < 3; ++d) c->rb_dils[j][d] = rd[d]; }
+    c->sample_rate = 16000; c->decoder_precision = EV_PREC_F16; c->keep_stages = 0;
+}
+
+const char* ev_last_error(ev_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
+    if (!cfg || !out) return fail(nullptr, "ev_create: null argument");
+    if (cfg->abi_version != EV_ABI_VERSION) return fail(nullptr, "ev_create: abi_version %d != %d", cfg->abi_version, EV_ABI_VERSION);
+    if (cfg->hidden != 384 || cfg->heads != 8) return fail(nullptr, "ev_create: only hidden=384 / heads=8 (d_k=48) kernels are built");
+    if (cfg->hidden % 128 || cfg->n_mels > MEL_PAD) return fail(nullptr, "ev_create: unsupported shape");
+    for (int i = 0; i < cfg->n_up; ++i)
+        if (cfg->up_kernels[i] != 2 * cfg->up_rates[i] || (cfg->up_rates[i] & (cfg->up_rates[i] - 1)))
+            return fail(nullptr, "ev_create: upsample stage %d must have kernel = 2*stride and a power-of-two stride", i);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, "ev_create: device %d out of range (%d devices)", device_id, ndev);
+    ev_handle* h = new ev_handle();
+    h->cfg = *cfg; h->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, "ev_create: cannot create stream on device %d", device_id);
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return 0;
+}
+
+void ev_destroy(ev_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; ++i) if (h->arena[i]) (void)hipFree(h->arena[i]);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->wblob && h->wblob_owned) (void)hipFree(h->wblob);
+    for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+    for (auto& kv : h->region_evt) { (void)hipEventDestroy(kv.second.first); (void)hipEventDestroy(kv.second.second); }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int ev_set_stream(ev_handle* h, void* s) {
+    if (!h) return -1;
+    (void)hipStreamSynchronize(h->stream);
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return 0;
+}
+
+int ev_load_weights(ev_handle* h, const void* blob, size_t nbytes, const char*) {
+    if (!h || !blob) return fail(h, "ev_load_weights: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->wblob && h->wblob_owned) HIPCHK(h, hipFree(h->wblob));
+    h->wblob = nullptr;
+    HIPCHK(h, hipMalloc((void**)&h->wblob, nbytes));
+    h->wblob_owned = true; h->wbytes = nbytes;
+    HIPCHK(h, hipMemcpy(h->wblob, blob, nbytes, hipMemcpyHostToDevice));
+    return parse_blob(h, (const char*)blob, nbytes);
+}
+
+int ev_load_weights_device(ev_handle* h, const void* dptr, size_t nbytes, const char*) {
+    if (!h || !dptr) return fail(h, "ev_load_weights_device: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->wblob && h->wblob_owned) HIPCHK(h, hipFree(h->wblob));
+    h->wblob = (char*)dptr; h->wblob_owned = false; h->wbytes = nbytes;
+    if (nbytes < 16) return fail(h, "weight blob too small");
+    uint32_t count = 0;
+    char hdr[16];
+    HIPCHK(h, hipMemcpy(hdr, dptr, 16, hipMemcpyDeviceToHost));
+    memcpy(&count, hdr + 8, 4);
+    const size_t tbl = 16 + (size_t)count * sizeof(BlobEntry);
+    if (tbl > nbytes) return fail(h, "weight blob: truncated table");
+    std::vector<char> host(tbl);
+    HIPCHK(h, hipMemcpy(host.data(), dptr, tbl, hipMemcpyDeviceToHost));
+    // parse_blob validates offsets against the full size
+    std::vector<char> fake(host);
+    return parse_blob(h, fake.data(), nbytes >= tbl ? nbytes : tbl) == 0 ? 0 : -1;
+}
+
+int ev_set_forced_durations(ev_handle* h, const int64_t* d, int64_t n) {
+    if (!h) return -1;
+    h->forced_dur.assign(d, d + n);
+    return 0;
+}
+
+int ev_memcpy_d2h(ev_handle* h, void* dst, const void* src, size_t n) {
+    if (!h || !dst || !src) return fail(h, "ev_memcpy_d2h: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ev_set_profiling(ev_handle* h, int enable) { if (!h) return -1; h->profiling = enable != 0; return 0; }
+int ev_get_timing(ev_handle* h, const char* name, float* ms) {
+    if (!h || !ms) return -1;
+    auto it = h->timings.find(name);
+    if (it == h->timings.end()) return fail(h, "no timing named %s", name);
+    *ms = it->second;
+    return 0;
+}
+int ev_kernel_stat_count(ev_handle* h) { return h ? (int)h->stats.size() : -1; }
+int ev_get_kernel_stat(ev_handle* h, int idx, ev_kernel_stat* out) {
+    if (!h || !out || idx < 0 || idx >= (int)h->stats.size()) return -1;
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", h->stats[idx].name.c_str());
+    out->launches = h->stats[idx].launches; out->ms = h->stats[idx].ms; out->flops = h->stats[idx].flops; out->bytes = h->stats[idx].bytes;
+    return 0;
+}
+
+// ------------------------------------------------------------------- vocoder-only entry
+static int finish_wav(ev_handle* h, VocBufs& vb, float* d_wav, int16_t* d_i16, int64_t* d_scr, uint32_t flags, ev_result* out) {
+    const int U = total_up(h->cfg);
+    if (pack_level(h, vb.wavrows.p, DT_F32, 1, 1, ilog2(U), false, d_wav, d_scr)) return -1;
+    if (flags & EV_FLAG_WANT_INT16) launch_wav_to_i16(d_wav, d_i16, h->total_frames * U, h->stream);
+    out->wav = d_wav;
+    out->wav_i16 = (flags & EV_FLAG_WANT_INT16) ? d_i16 : nullptr;
+    out->total_samples = h->total_frames * U;
+    return 0;
+}
+
+static void register_voc_taps(ev_handle* h, VocBufs& vb) {
+    const ev_config& c = h->cfg;
+    add_tap(h, "voc_pre", vb.pre_tap.p, DT_F32, c.up_init_ch, c.up_init_ch, 1, 0);
+    int ch = c.up_init_ch, U = 1;
+    for (int i = 0; i < c.n_up; ++i) {
+        U *= c.up_rates[i]; ch /= 2;
+        add_tap(h, ("voc_up" + std::to_string(i)).c_str(), vb.xu[i].p, DT_F16, ch, ch, 2 + i, ilog2(U));
+        add_tap(h, ("voc_mrf" + std::to_string(i)).c_str(), vb.mrf_tap[i].p, DT_F32, ch, ch, 2 + i, ilog2(U));
+    }
+}
+
+int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32_t* mel_lens, uint32_t flags, ev_result* out) {
+    if (!h || !mel || !mel_lens || !out || B <= 0) return fail(h, "ev_vocoder: bad argument");
+    if (h->wt.empty()) return fail(h, "ev_vocoder: weights not loaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    const ev_config& c = h->cfg;
+    const bool keep = c.keep_stages != 0;
+    const int U = total_up(c);
+    profiling_reset(h);
+    h->taps.clear();
+    h->B = B; h->total_tokens = 0;
+    h->mel_lens.assign(mel_lens, mel_lens + B);
+    for (int b = 0; b < B; ++b) if (mel_lens[b] <= 0) return fail(h, "ev_vocoder: mel_lens[%d] = %d", b, mel_lens[b]);
+    std::vector<int64_t> elem_off(B);
+    int64_t eo = 0;
+    for (int b = 0; b < B; ++b) { elem_off[b] = eo; eo += (int64_t)c.n_mels * mel_lens[b]; }
+    const size_t es = mel_is_f16 ? 2 : 4;
+
+    Buf mel16; VocBufs vb; float* d_wav = nullptr; int16_t* d_i16 = nullptr; int64_t* d_scr = nullptr; int64_t* d_eoff = nullptr;
+    void* d_melin = nullptr; int Rf = 0;
+    { int64_t rows = GAP; for (int b = 0; b < B; ++b) rows += mel_lens[b] + GAP; Rf = (int)align_up((size_t)rows, ROW_ALIGN); }
+    if (pinned_reserve(h, (size_t)Rf * 9 + (size_t)B * 16 + 1024)) return -1;
+    size_t need = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        ArenaPlan ap{h, 1, pass == 0};
+        if (pass == 1 && arena_reserve(h, 1, need)) return -1;
+        build_frame_layout(h, ap, pass == 0, B);
+        h->d_mel_len = ap.arr<int32_t>(B);
+        d_eoff = ap.arr<int64_t>(B);
+        d_scr = ap.arr<int64_t>(3 * (size_t)B + 8);
+        if (!(flags & EV_FLAG_DEVICE_INPUTS)) d_melin = ap.take((size_t)eo * es);
+        mel16 = ap.rows(Rf, MEL_PAD, 2);
+        plan_vocoder(ap, c, Rf, keep, vb);
+        d_wav = ap.arr<float>((size_t)h->total_frames * U);
+        d_i16 = ap.arr<int16_t>((size_t)h->total_frames * U);
+        need = ap.off;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_mel_len, mel_lens, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_eoff, elem_off.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+    const void* melsrc = mel;
+    if (!(flags & EV_FLAG_DEVICE_INPUTS)) { HIPCHK(h, hipMemcpyAsync(d_melin, mel, (size_t)eo * es, hipMemcpyHostToDevice, h->stream)); melsrc = d_melin; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    region_begin(h, "total");
+    launch_mel_to_rows(melsrc, mel_is_f16, d_eoff, h->d_frm_seq, h->d_frm_pos, h->d_mel_len, mel16.p, Rf, c.n_mels, MEL_PAD, h->stream);
+    region_begin(h, "vocoder");
+    if (run_vocoder(h, mel16, Rf, (double)h->total_frames, vb, keep)) return -1;
+    region_end(h, "vocoder");
+    memset(out, 0, sizeof *out);
+    if (finish_wav(h, vb, d_wav, d_i16, d_scr, flags, out)) return -1;
+    region_end(h, "total");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    profiling_collect(h);
+    if (keep) register_voc_taps(h, vb);
+    out->batch = B; out->total_frames = h->total_frames; out->mel_lens = h->mel_lens.data(); out->mel_offsets = h->mel_offs.data();
+    return 0;
+}
+
+// ------------------------------------------------------------------- full synthesis
+int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, const int64_t* speaker, const float* style,
+                  const float* content, float alpha, uint32_t flags, ev_result* out) {
+    if (!h || !ling || !cu || !speaker || !style || !content || !out || B <= 0) return fail(h, "ev_synthesize: bad argument");
+    if (h->wt.empty()) return fail(h, "ev_synthesize: weights not loaded");
+    if (cu[0] != 0) return fail(h, "ev_synthesize: cu_seqlens[0] must be 0");
+    HIPCHK(h, hipSetDevice(h->device));
+    const ev_config& c = h->cfg;
+    const int C = c.hidden, U = total_up(c);
+    const bool keep = c.keep_stages != 0;
+    const bool dev_in = (flags & EV_FLAG_DEVICE_INPUTS) != 0;
+    const int dec_prec = c.decoder_precision == EV_PREC_F32 ? DT_F32 : DT_F16;
+    profiling_reset(h);
+    h->taps.clear();
+    h->B = B;
+    const int NT = cu[B];
+    h->total_tokens = NT;
+    int max_tok = 0;
+    h->tok_off.resize(B); h->tok_len.resize(B);
+    int64_t rows = GAP;
+    for (int b = 0; b < B; ++b) {
+        const int n = cu[b + 1] - cu[b];
+        if (n <= 0) return fail(h, "ev_synthesize: utterance %d has %d tokens", b, n);
+        h->tok_off[b] = (int32_t)rows; h->tok_len[b] = n; rows += n + GAP; max_tok = std::max(max_tok, n);
+    }
+    const int Rt = (int)align_up((size_t)rows, ROW_ALIGN);
+    h->Rt = Rt;
+    if ((flags & EV_FLAG_FORCED_DURATIONS) && (int64_t)h->forced_dur.size() != NT) return fail(h, "forced durations: expected %d values", NT);
+    WPTR(pe, float, "pe");
+    const WeightEntry* pew = W(h, "pe");
+    const int pe_len = (int)pew->dims[0];
+    if (max_tok > pe_len) return fail(h, "utterance longer than the packed positional table (%d > %d)", max_tok, pe_len);
+
+    // ---------------- phase 1: token-rate arena
+    struct TokBufs {
+        Buf x, hb, qkv, ctx, ffn, y, xp, xvar, t1, t2, pitch, energy, logd, centre;
+        std::vector<Buf> ltaps; Buf tokemb_tap;
+        int64_t* d_ling; int64_t* d_spk; float* d_style; float* d_content; float* d_u;
+        int64_t* d_dur; float* d_logd_packed; float* d_pitch_packed; float* d_energy_packed; int64_t* d_forced; int64_t* d_scr;
+    } tb;
+    size_t tok_arena_end = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        ArenaPlan ap{h, 0, pass == 0};
+        if (pass == 1 && arena_reserve(h, 0, tok_arena_end)) return -1;
+        h->d_tok_seq = ap.arr<int32_t>(Rt); h->d_tok_pos = ap.arr<int32_t>(Rt); h->d_tok_valid = ap.arr<uint8_t>(Rt);
+        h->d_tok_off = ap.arr<int32_t>(B); h->d_tok_len = ap.arr<int32_t>(B); h->d_cu = ap.arr<int32_t>(B + 1);
+        h->d_mel_len = ap.arr<int32_t>(B);
+        tb.d_ling = ap.arr<int64_t>(NT); tb.d_spk = ap.arr<int64_t>(B); tb.d_style = ap.arr<float>((size_t)B * c.bert_dim);
+        tb.d_content = ap.arr<float>((size_t)B * c.bert_dim); tb.d_u = ap.arr<float>((size_t)B * C);
+        tb.d_dur = ap.arr<int64_t>(NT); tb.d_logd_packed = ap.arr<float>(NT); tb.d_pitch_packed = ap.arr<float>(NT);
+        tb.d_energy_packed = ap.arr<float>(NT); tb.d_forced = ap.arr<int64_t>(NT); tb.d_scr = ap.arr<int64_t>(3 * (size_t)B + 8);
+        tb.x = ap.rows(Rt, C, 4); tb.hb = ap.rows(Rt, C, 4); tb.qkv = ap.rows(Rt, 3 * C, 4); tb.ctx = ap.rows(Rt, C, 4);
+        tb.ffn = ap.rows(Rt, 4 * C, 4); tb.y = ap.rows(Rt, C, 4); tb.xp = ap.rows(Rt, C, 4); tb.xvar = ap.rows(Rt, C, 4);
+        tb.t1 = ap.rows(Rt, C, 4); tb.t2 = ap.rows(Rt, C, 4);
+        tb.pitch = ap.rows(Rt, 1, 4); tb.energy = ap.rows(Rt, 1, 4); tb.logd = ap.rows(Rt, 1, 4); tb.centre = ap.rows(Rt, 1, 4);
+        if (keep) { tb.ltaps.resize(c.enc_layers); for (auto& b : tb.ltaps) b = ap.rows(Rt, C, 4); tb.tokemb_tap = ap.rows(Rt, C, 4); }
+        tok_arena_end = ap.off;
+    }
+    // host-side token maps
+    if (pinned_reserve(h, (size_t)Rt * 9 + (size_t)B * 64 + 1024)) return -1;
+    {
+        int32_t* seq = (int32_t*)h->pinned; int32_t* pos = seq + Rt; int32_t* off = pos + Rt; int32_t* len = off + B; uint8_t* valid = (uint8_t*)(len + B);
+        for (int r = 0; r < Rt; ++r) { seq[r] = -1; pos[r] = 0; valid[r] = 0; }
+        for (int b = 0; b < B; ++b) {
+            off[b] = h->tok_off[b]; len[b] = h->tok_len[b];
+            for (int j = 0; j < h->tok_len[b]; ++j) { const int r = h->tok_off[b] + j; seq[r] = b; pos[r] = j; valid[r] = 1; }
+        }
+        HIPCHK(h, hipMemcpyAsync(h->d_tok_seq, seq, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_tok_pos, pos, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_tok_off, off, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_tok_len, len, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_tok_valid, valid, (size_t)Rt, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_cu, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        const hipMemcpyKind kind = dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIPCHK(h, hipMemcpyAsync(tb.d_ling, ling, (size_t)NT * 8, kind, h->stream));
+        HIPCHK(h, hipMemcpyAsync(tb.d_spk, speaker, (size_t)B * 8, kind, h->stream));
+        HIPCHK(h, hipMemcpyAsync(tb.d_style, style, (size_t)B * c.bert_dim * 4, kind, h->stream));
+        HIPCHK(h, hipMemcpyAsync(tb.d_content, content, (size_t)B * c.bert_dim * 4, kind, h->stream));
+        if (flags & EV_FLAG_FORCED_DURATIONS)
+            HIPCHK(h, hipMemcpyAsync(tb.d_forced, h->forced_dur.data(), (size_t)NT * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    region_begin(h, "total");
+    region_begin(h, "am");
+    region_begin(h, "encoder");
+    RowCtx trc{Rt, h->d_tok_valid, h->d_tok_seq, h->d_tok_off, h->d_tok_len, B, max_tok, (double)NT};
+    WPTR(tok_emb, float, "tok_emb"); WPTR(spk_emb, float, "spk_emb");
+    float alphas[2];
+    if (get_scalar(h, "enc.alpha", &alphas[0]) || get_scalar(h, "dec.alpha", &alphas[1])) return -1;
+    { KScope ks(h, "embed_pe", 0, (double)NT * C * 12.0);
+      launch_embed_pe(tb.d_ling, h->d_cu, h->d_tok_seq, h->d_tok_pos, tok_emb, pe, alphas[0], (float*)tb.x.p, keep ? (float*)tb.tokemb_tap.p : nullptr, Rt, C, h->stream); }
+    if (run_stack(h, "enc", c.enc_layers, DT_F32, trc, tb.x, tb.hb, tb.qkv, tb.ctx, tb.ffn, tb.y, nullptr, keep ? &tb.ltaps : nullptr)) return -1;
+    region_end(h, "encoder");
+    region_begin(h, "variance");
+    // embed_projection1 (model_open_source.py:109-111): time-varying part as a GEMM, conditioning part as a per-utterance vector
+    WPTR(wcond, float, "proj.wcond"); WPTR(bproj, float, "proj.b"); WPTR(wproj, char, "proj.w32");
+    { KScope ks(h, "cond_vector", 2.0 * B * C * (C + 2.0 * c.bert_dim), 0);
+      launch_cond_vector(tb.d_spk, tb.d_style, tb.d_content, spk_emb, wcond, bproj, tb.d_u, B, C, c.bert_dim, h->stream); }
+    {
+        ConvGemmParams p = gemm_defaults();
+        p.dtype = DT_F32; p.A = tb.y.p; p.lda = C; p.W = wproj; p.M = Rt; p.N = C; p.K = C; p.row_valid = h->d_tok_valid;
+        p.row_seq = h->d_tok_seq; p.seq_bias = tb.d_u; p.ld_seq_bias = C; p.out32 = (float*)tb.xp.p; p.ldo = C;
+        if (gemm(h, "variance_f32_gemm", p, NT)) return -1;
+    }
+    if (run_predictor(h, "pitch", c.pitch_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.pitch.p)) return -1;
+    if (run_predictor(h, "energy", c.energy_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.energy.p)) return -1;
+    if (run_predictor(h, "dur", c.dur_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.logd.p)) return -1;
+    {
+        WPTR(wp, float, "pitch_emb.w"); WPTR(bp, float, "pitch_emb.b"); WPTR(we, float, "energy_emb.w"); WPTR(be, float, "energy_emb.b");
+        KScope ks(h, "var_embed_add", 0, (double)NT * C * 8.0);
+        launch_var_embed_add((const float*)tb.xp.p, (const float*)tb.pitch.p, (const float*)tb.energy.p, wp, bp, we, be, h->d_tok_valid,
+                             (float*)tb.xvar.p, Rt, C, c.var_embed_kernel, h->stream);
+    }
+    { KScope ks(h, "durations", 0, 0);
+      launch_durations((const float*)tb.logd.p, h->d_tok_off, h->d_tok_len, B, alpha, (flags & EV_FLAG_FORCED_DURATIONS) ? tb.d_forced : nullptr,
+                       h->d_cu, tb.d_dur, tb.d_logd_packed, (float*)tb.centre.p, h->d_mel_len, h->stream); }
+    region_end(h, "variance");
+    // the reference has the same host sync here (alignment.py:195 `.item()`)
+    h->mel_lens.resize(B);
+    HIPCHK(h, hipMemcpyAsync(h->mel_lens.data(), h->d_mel_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int max_frames = 0;
+    for (int b = 0; b < B; ++b) {
+        if (h->mel_lens[b] <= 0) return fail(h, "utterance %d produced %d mel frames", b, h->mel_lens[b]);
+        max_frames = std::max(max_frames, h->mel_lens[b]);
+    }
+    if (max_frames > pe_len) return fail(h, "utterance longer than the packed positional table (%d frames > %d)", max_frames, pe_len);
+
+    // ---------------- phase 2: frame-rate arena (placed after the token arena)
+    struct FrmBufs { Buf x, hb, qkv, ctx, ffn, y, mel32, mel16, up_tap, y_tap; std::vector<Buf> ltaps; float* d_mel; float* d_wav; int16_t* d_i16; } fb;
+    VocBufs vb;
+    int Rf = 0;
+    const size_t esd = dec_prec == DT_F16 ? 2 : 4;
+    { int64_t r = GAP; for (int b = 0; b < B; ++b) r += h->mel_lens[b] + GAP; Rf = (int)align_up((size_t)r, ROW_ALIGN); }
+    if (pinned_reserve(h, (size_t)Rf * 9 + (size_t)B * 16 + 1024)) return -1;
+    size_t frm_need = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        ArenaPlan ap{h, 1, pass == 0};
+        if (pass == 1 && arena_reserve(h, 1, frm_need)) return -1;
+        build_frame_layout(h, ap, pass == 0, B);
+        fb.x = ap.rows(Rf, C, 4); fb.hb = ap.rows(Rf, C, esd); fb.qkv = ap.rows(Rf, 3 * C, esd); fb.ctx = ap.rows(Rf, C, esd);
+        fb.ffn = ap.rows(Rf, 4 * C, esd); fb.y = ap.rows(Rf, C, esd); fb.mel32 = ap.rows(Rf, MEL_PAD, 4); fb.mel16 = ap.rows(Rf, MEL_PAD, 2);
+        if (keep) { fb.ltaps.resize(c.dec_layers); for (auto& b : fb.ltaps) b = ap.rows(Rf, C, 4); fb.up_tap = ap.rows(Rf, C, 4); fb.y_tap = ap.rows(Rf, C, 4); }
+        fb.d_mel = ap.arr<float>((size_t)h->total_frames * c.n_mels);
+        if (!(flags & EV_FLAG_NO_VOCODER)) {
+            plan_vocoder(ap, c, Rf, keep, vb);
+            fb.d_wav = ap.arr<float>((size_t)h->total_frames * U);
+            fb.d_i16 = ap.arr<int16_t>((size_t)h->total_frames * U);
+        }
+        frm_need = ap.off;
+    }
+    h->Rf = Rf;
+    region_begin(h, "decoder");
+    RowCtx frc{Rf, h->d_frm_valid, h->d_frm_seq, h->d_frm_off, h->d_mel_len, B, max_frames, (double)h->total_frames};
+    { KScope ks(h, "gauss_upsample", 0, (double)h->total_frames * C * 8.0);
+      launch_gauss_upsample((const float*)tb.xvar.p, (const float*)tb.centre.p, h->d_tok_off, h->d_tok_len, h->d_frm_seq, h->d_frm_pos, pe,
+                            alphas[1], 0.1f, (float*)fb.x.p, keep ? (float*)fb.up_tap.p : nullptr, Rf, C, h->stream); }
+    if (run_stack(h, "dec", c.dec_layers, dec_prec, frc, fb.x, fb.hb, fb.qkv, fb.ctx, fb.ffn, fb.y,
+                  (keep && dec_prec == DT_F16) ? (float*)fb.y_tap.p : nullptr, keep ? &fb.ltaps : nullptr)) return -1;
+    {
+        WPTR(wm, char, dec_prec == DT_F16 ? "to_mel.w16" : "to_mel.w32"); WPTR(bm, float, "to_mel.b");
+        ConvGemmParams p = gemm_defaults();
+        p.dtype = dec_prec; p.A = fb.y.p; p.lda = C; p.W = wm; p.bias = bm; p.M = Rf; p.N = MEL_PAD; p.K = C; p.row_valid = h->d_frm_valid;
+        p.out32 = (float*)fb.mel32.p; p.out16 = fb.mel16.p; p.ldo = MEL_PAD;
+        if (gemm(h, dec_prec == DT_F16 ? "dec_f16_gemm" : "dec_f32_gemm", p, (double)h->total_frames)) return -1;
+    }
+    region_end(h, "decoder");
+    region_end(h, "am");
+    // packed outputs
+    if (pack_level(h, fb.mel32.p, DT_F32, MEL_PAD, c.n_mels, 0, false, fb.d_mel, tb.d_scr)) return -1;
+    if (pack_level(h, tb.pitch.p, DT_F32, 1, 1, 0, true, tb.d_pitch_packed, tb.d_scr)) return -1;
+    if (pack_level(h, tb.energy.p, DT_F32, 1, 1, 0, true, tb.d_energy_packed, tb.d_scr)) return -1;
+    memset(out, 0, sizeof *out);
+    if (!(flags & EV_FLAG_NO_VOCODER)) {
+        region_begin(h, "vocoder");
+        if (run_vocoder(h, fb.mel16, Rf, (double)h->total_frames, vb, keep)) return -1;
+        region_end(h, "vocoder");
+        if (finish_wav(h, vb, fb.d_wav, fb.d_i16, tb.d_scr, flags, out)) return -1;
+    }
+    region_end(h, "total");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    profiling_collect(h);
+    if (keep) {
+        add_tap(h, "tok_emb", tb.tokemb_tap.p, DT_F32, C, C, 0, 0);
+        for (int i = 0; i < c.enc_layers; ++i) add_tap(h, ("enc_l" + std::to_string(i)).c_str(), tb.ltaps[i].p, DT_F32, C, C, 0, 0);
+        add_tap(h, "enc_out", tb.y.p, DT_F32, C, C, 0, 0);
+        add_tap(h, "x_proj", tb.xp.p, DT_F32, C, C, 0, 0);
+        add_tap(h, "x_var", tb.xvar.p, DT_F32, C, C, 0, 0);
+        add_tap(h, "upsampled", fb.up_tap.p, DT_F32, C, C, 1, 0);
+        for (int i = 0; i < c.dec_layers; ++i) add_tap(h, ("dec_l" + std::to_string(i)).c_str(), fb.ltaps[i].p, DT_F32, C, C, 1, 0);
+        if (dec_prec == DT_F16) add_tap(h, "dec_out", fb.y_tap.p, DT_F32, C, C, 1, 0);
+        else add_tap(h, "dec_out", fb.y.p, DT_F32, C, C, 1, 0);
+        add_tap(h, "mel", fb.mel32.p, DT_F32, MEL_PAD, c.n_mels, 1, 0);
+        if (!(flags & EV_FLAG_NO_VOCODER)) register_voc_taps(h, vb);
+    }
+    out->batch = B; out->total_tokens = NT; out->total_frames = h->total_frames;
+    out->mel = fb.d_mel; out->durations = tb.d_dur; out->log_durations = tb.d_logd_packed; out->pitch = tb.d_pitch_packed;
+    out->energy = tb.d_energy_packed; out->mel_lens = h->mel_lens.data(); out->mel_offsets = h->mel_offs.data();
+    h->last_dur = tb.d_dur;
+    return 0;
+}
+
+int64_t ev_get_stage(ev_handle* h, const char* name, void* host_dst, size_t cap) {
+    if (!h || !name) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!strcmp(name, "dur")) {
+        const size_t need = (size_t)h->total_tokens * 8;
+        if (!host_dst) return (int64_t)need;
+        if (cap < need || !h->last_dur) return fail(h, "ev_get_stage(dur): buffer too small or no synthesis yet");
+        HIPCHK(h, hipMemcpy(host_dst, h->last_dur, need, hipMemcpyDeviceToHost));
+        return (int64_t)need;
+    }
+    if (!strcmp(name, "mel_len")) {
+        const size_t need = (size_t)h->B * 8;
+        if (!host_dst) return (int64_t)need;
+        if (cap < need) return fail(h, "ev_get_stage(mel_len): buffer too small");
+        for (int b = 0; b < h->B; ++b) ((int64_t*)host_dst)[b] = h->mel_lens[b];
+        return (int64_t)need;
+    }
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return fail(h, "ev_get_stage: unknown stage '%s' (keep_stages=%d)", name, h->cfg.keep_stages);
+    const Tap& t = it->second;
+    int64_t nrows = 0;
+    for (int b = 0; b < h->B; ++b) nrows += t.level == 0 ? h->tok_len[b] : ((int64_t)h->mel_lens[b] << t.shift);
+    const size_t need = (size_t)nrows * t.C * 4;
+    if (!host_dst) return (int64_t)need;
+    if (cap < need) return fail(h, "ev_get_stage(%s): need %zu bytes, cap %zu", name, need, cap);
+    float* d_tmp = nullptr; int64_t* d_scr = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_tmp, need));
+    HIPCHK(h, hipMalloc((void**)&d_scr, (3 * (size_t)h->B + 8) * 8));
+    int rc = pack_level(h, t.ptr, t.dtype, t.ld, t.C, t.shift, t.level == 0, d_tmp, d_scr);
+    if (rc == 0 && hipMemcpy(host_dst, d_tmp, need, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, "ev_get_stage: D2H failed");
+    (void)hipFree(d_tmp); (void)hipFree(d_scr);
+    return rc ? -1 : (int64_t)need;
+}
+
+// ------------------------------------------------------------------- per-kernel test entry points (include/evhip_ops.h)
+int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* stream) {
+    static_assert(sizeof(ev_conv_gemm_desc) == sizeof(ConvGemmParams), "descriptor layout must match ConvGemmParams");
+    ConvGemmParams p;
+    memcpy(&p, d, sizeof p);
+    const int es = p.dtype == DT_F16 ? 2 : 4;
+    if (p.M % ROW_ALIGN || p.N % 32 || (p.K * es) % 64 || (p.taps - 1) * p.dil > 64) return -2;
+    launch_conv_gemm(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, const uint8_t* row_valid,
+                    void* out16, float* out32, const float* dot_w, float dot_b, float* dot_out, void* stream) {
+    LayerNormParams p{};
+    p.x = x; p.ldx = C; p.rows = rows; p.C = C; p.gamma = gamma; p.beta = beta; p.eps = eps; p.row_valid = row_valid; p.out16 = out16;
+    p.out32 = out32; p.ldo = C; p.dot_w = dot_w; p.dot_b = dot_b; p.dot_out = dot_out;
+    launch_layernorm(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int ev_op_attention(const void* qkv, int is_f16, int C, int heads, const int32_t* seq_off, const int32_t* seq_len, int B, int max_len,
+                    void* out, void* stream) {
+    AttnParams p{};
+    p.qkv = qkv; p.dtype = is_f16 ? DT_F16 : DT_F32; p.ld = 3 * C; p.C = C; p.heads = heads; p.seq_off = seq_off; p.seq_len = seq_len;
+    p.B = B; p.max_len = max_len; p.out = out; p.ldo = C;
+    launch_attention(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // extern "C"

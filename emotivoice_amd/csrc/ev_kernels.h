@@ -1,0 +1,102 @@
+// Internal launcher interface between the engine (ev_engine.cpp) and the gfx950 kernels.
+// Not part of the public ABI (that is include/evhip.h); the ev_op_* C wrappers in
+// include/evhip_ops.h expose these launchers to the per-kernel parity tests.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ev {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LRELU = 3, ACT_TANH = 4 };
+enum DType { DT_F16 = 0, DT_F32 = 1 };
+
+// out[m, n] = post( scale * ( act( sum_{tap,k} pro(A[m + (tap-center)*dil, k]) * W[n][tap][k] + bias[n] )
+//                              + seq_bias[row_seq[m]][n] + res[m, n] ) + acc32[m, n] )
+// rows with row_valid[m >> valid_shift] == 0 are written as exact zeros.
+// Channels-last activations ([rows][channels]); the conv over time is an implicit GEMM whose
+// M dimension is time.  Reference ops covered: nn.Linear, Conv1d (any k / dilation, "same" pad),
+// ConvTranspose1d(k = 2*stride, pad = stride/2) as a 3-tap conv with N = stride*C_out.
+struct ConvGemmParams {
+    int dtype;              // DT_F16: A/W fp16, MFMA f32_16x16x32_f16; DT_F32: A/W fp32, MFMA f32_16x16x4_f32 (exact fp32)
+    const void* A; int lda; // activations, row pitch in elements; rows [-64, M+64) must be readable
+    const void* W;          // [N][taps][K], K contiguous
+    const float* bias;      // [N] or null
+    int M, N, K, taps, dil, center;
+    const uint8_t* row_valid; int valid_shift;   // null -> all rows valid
+    const int32_t* row_seq; const float* seq_bias; int ld_seq_bias;   // per-utterance additive vector, or null
+    int act; float act_slope;
+    int pro_lrelu; float pro_slope;              // leaky-relu applied to A while staging
+    const void* res; int res_dtype; int ldres;   // residual (fp16 or fp32) or null
+    float out_scale;
+    const float* acc32; int ldacc;               // fp32 accumulate-in (after scaling) or null
+    int post_lrelu; float post_slope;
+    void* out16; float* out32; int ldo;          // either / both outputs
+    int out32_before_post;                       // out32 receives the value BEFORE post_lrelu (stage taps)
+};
+void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
+
+// LayerNorm over the channel dim (eps 1e-12, reference modules/encoder.py:112-127), fp32 in.
+// out16/out32 optional; if dot_w != null additionally dot_out[r] = <LN(x[r]), dot_w> + dot_b.
+struct LayerNormParams {
+    const float* x; int ldx; int rows; int C;
+    const float* gamma; const float* beta; float eps;
+    const uint8_t* row_valid;
+    void* out16; float* out32; int ldo;
+    const float* dot_w; float dot_b; float* dot_out;
+};
+void launch_layernorm(const LayerNormParams& p, hipStream_t s);
+
+// token embedding gather + alpha * PE[pos] (reference model_open_source.py:107, encoder.py:257-261)
+void launch_embed_pe(const int64_t* ling_packed, const int32_t* cu_seqlens_dev, const int32_t* row_seq /* -1 = gap */,
+                     const int32_t* row_pos, const float* emb, const float* pe, float alpha, float* out, float* tap_out,
+                     int rows, int C, hipStream_t s);
+
+// Self-attention, one (utterance, head, 64-query tile) per wave; fp32 math, online softmax.
+// qkv: [rows][3*C] (fp16 or fp32) with q | k | v column blocks; out: [rows][C].
+struct AttnParams {
+    const void* qkv; int dtype; int ld; int C; int heads;
+    const int32_t* seq_off; const int32_t* seq_len; int B; int max_len;
+    void* out; int ldo;     // same dtype as qkv
+};
+void launch_attention(const AttnParams& p, hipStream_t s);
+
+// u[b, :] = bias + Wspk . spk_emb[speaker[b]] + Wsty . style[b] + Wcon . content[b]
+// (columns 384..2303 of embed_projection1, reference model_open_source.py:110-111)
+void launch_cond_vector(const int64_t* speaker, const float* style, const float* content, const float* spk_emb,
+                        const float* Wcond /* [C][C + 2*bert] */, const float* bias, float* u, int B, int C, int bert,
+                        hipStream_t s);
+
+// x_var = x_proj + pitch_embed(pitch) + energy_embed(energy)   (Conv1d 1->C, k taps, zero pad; :131-134)
+void launch_var_embed_add(const float* x, const float* pitch, const float* energy, const float* wp, const float* bp,
+                          const float* we, const float* be, const uint8_t* row_valid, float* out, int rows, int C, int k,
+                          hipStream_t s);
+
+// durations: d = max(rint(exp(log_d) - 1), 0) (variance.py:47-51); all-zero guard, cumsum, centres
+// (alignment.py:183-202).  One block per utterance, wavefront prefix sum.
+void launch_durations(const float* log_d /* token rows */, const int32_t* tok_off, const int32_t* tok_len, int B,
+                      float alpha, const int64_t* forced /* packed or null */, const int32_t* cu_seqlens_dev,
+                      int64_t* dur_packed, float* logd_packed, float* centre_rows, int32_t* mel_len, hipStream_t s);
+
+// Gaussian upsampling (alignment.py:204-210) + decoder positional encoding (encoder.py:257-261).
+void launch_gauss_upsample(const float* xvar, const float* centre_rows, const int32_t* tok_off, const int32_t* tok_len,
+                           const int32_t* frm_row_seq, const int32_t* frm_row_pos, const float* pe, float pe_alpha,
+                           float delta, float* out, float* tap_out, int rows, int C, hipStream_t s);
+
+// mel (B x (n_mels, T_b), fp32/fp16) -> channels-last fp16 [rows][ldo] with zero gaps and zero pad channels
+void launch_mel_to_rows(const void* mel, int is_f16, const int64_t* mel_elem_off, const int32_t* frm_row_seq,
+                        const int32_t* frm_row_pos, const int32_t* mel_len, void* out16, int rows, int n_mels, int ldo,
+                        hipStream_t s);
+
+// conv_post: leaky-relu'd input [rows][C] fp16 -> Conv1d(C->1, k) -> tanh -> wav fp32 (+ int16)
+void launch_conv_post(const void* x16, int ldx, const float* w /* [k][C] */, float bias, int k, const uint8_t* row_valid,
+                      int valid_shift, float* wav_rows, int rows, int C, hipStream_t s);
+
+// gather valid rows of a [rows][ld] buffer (fp16 or fp32) into a packed fp32 [n_valid][C] host-visible buffer
+void launch_pack_rows(const void* src, int dtype, int ld, int C, const int64_t* seq_row_off /* per utterance first row */,
+                      const int64_t* seq_out_off /* per utterance packed offset (rows) */, const int32_t* seq_rows, int B,
+                      int64_t max_rows, float* dst, hipStream_t s);
+
+void launch_wav_to_i16(const float* wav, int16_t* out, int64_t n, hipStream_t s);
+void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+
+}  // namespace ev

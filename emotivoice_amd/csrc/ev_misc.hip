@@ -1,0 +1,547 @@
+// Non-GEMM kernels of the EmotiVoice hot path for gfx950 (wave = 64 lanes).
+// All activations are channels-last [rows][channels]; "rows" follow the gap layout described in
+// DESIGN.md (utterances separated by >= 4 zero rows; invalid rows are always written as zeros).
+#include <hip/hip_fp16.h>
+
+#include "ev_kernels.h"
+
+namespace ev {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------ LayerNorm (+ optional dot head)
+// reference modules/encoder.py:112-127 (eps = 1e-12); variance.py:29-33 (channel LN in predictors);
+// variance.py:46,119 (Linear(C,1) head fused as dot_w/dot_b).  One wave per row, C <= 512, C % 128 == 0.
+__global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= p.rows) return;
+    const int nv = p.C >> 7;   // float2 chunks per lane
+    const bool valid = p.row_valid ? p.row_valid[row] != 0 : true;
+    float2 v[4];
+    float s = 0.f;
+    const float* xr = p.x + (long)row * p.ldx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nv) {
+            v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2);
+            s += v[i].x + v[i].y;
+        }
+    }
+    const float mean = wave_sum(s) / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean;
+            q += a * a + b * b;
+        }
+    }
+    const float var = wave_sum(q) / (float)p.C;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nv) {
+            const int c = i * 128 + lane * 2;
+            const float2 g = *reinterpret_cast<const float2*>(p.gamma + c);
+            const float2 b = *reinterpret_cast<const float2*>(p.beta + c);
+            float y0 = (v[i].x - mean) * rstd * g.x + b.x;
+            float y1 = (v[i].y - mean) * rstd * g.y + b.y;
+            if (!valid) { y0 = 0.f; y1 = 0.f; }
+            if (p.dot_w) {
+                const float2 w = *reinterpret_cast<const float2*>(p.dot_w + c);
+                dot += y0 * w.x + y1 * w.y;
+            }
+            if (p.out32) *reinterpret_cast<float2*>(p.out32 + (long)row * p.ldo + c) = make_float2(y0, y1);
+            if (p.out16) *reinterpret_cast<__half2*>(reinterpret_cast<__half*>(p.out16) + (long)row * p.ldo + c) = __floats2half2_rn(y0, y1);
+        }
+    }
+    if (p.dot_w) {
+        dot = wave_sum(dot);
+        if (lane == 0) p.dot_out[row] = valid ? dot + p.dot_b : 0.f;
+    }
+}
+void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------ embedding + positional encoding
+// reference model_open_source.py:107 (src_word_emb) and modules/encoder.py:257-261 (x + alpha * pe[t])
+__global__ __launch_bounds__(256) void embed_pe_kernel(const int64_t* ling, const int32_t* cu, const int32_t* row_seq,
+                                                       const int32_t* row_pos, const float* emb, const float* pe, float alpha,
+                                                       float* out, float* tap, int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = row_seq[row];
+    float* o = out + (long)row * C;
+    if (b < 0) {
+        for (int c = lane * 2; c < C; c += 128) {
+            *reinterpret_cast<float2*>(o + c) = make_float2(0.f, 0.f);
+            if (tap) *reinterpret_cast<float2*>(tap + (long)row * C + c) = make_float2(0.f, 0.f);
+        }
+        return;
+    }
+    const int pos = row_pos[row];
+    const long tok = ling[cu[b] + pos];
+    const float* e = emb + tok * C;
+    const float* pr = pe + (long)pos * C;
+    for (int c = lane * 2; c < C; c += 128) {
+        const float2 ev = *reinterpret_cast<const float2*>(e + c);
+        const float2 pv = *reinterpret_cast<const float2*>(pr + c);
+        if (tap) *reinterpret_cast<float2*>(tap + (long)row * C + c) = ev;
+        *reinterpret_cast<float2*>(o + c) = make_float2(ev.x + alpha * pv.x, ev.y + alpha * pv.y);
+    }
+}
+void launch_embed_pe(const int64_t* ling, const int32_t* cu, const int32_t* row_seq, const int32_t* row_pos, const float* emb,
+                     const float* pe, float alpha, float* out, float* tap_out, int rows, int C, hipStream_t s) {
+    hipLaunchKernelGGL(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ling, cu, row_seq, row_pos, emb, pe, alpha, out,
+                       tap_out, rows, C);
+}
+
+// ------------------------------------------------------------------ self-attention (fp32 math)
+// reference modules/encoder.py:72-109: softmax(q k^T / sqrt(dk)) v, restricted to the utterance's own
+// rows (B = 1 semantics; decoder runs with mask=None over its own frames, model_open_source.py:145-146).
+// One wave = 64 consecutive queries of one (utterance, head); keys/values are streamed through LDS
+// in tiles of 64 with an online softmax (chunks of 8 keys per rescale).
+template <typename T, int DK>
+__global__ __launch_bounds__(64) void attention_kernel(const AttnParams p) {
+    constexpr int KP = DK + 4;   // padded LDS row (floats)
+    __shared__ __attribute__((aligned(16))) float Ks[64 * KP];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * KP];
+    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    const int len = p.seq_len[b];
+    if (qt * 64 >= len) return;
+    const int lane = threadIdx.x;
+    const long row0 = p.seq_off[b];
+    const int qi = qt * 64 + lane;
+    const bool qvalid = qi < len;
+    const T* base = reinterpret_cast<const T*>(p.qkv);
+    const float scale = 1.0f / sqrtf((float)DK);
+
+    float q[DK], o[DK];
+#pragma unroll
+    for (int d = 0; d < DK; ++d) { q[d] = 0.f; o[d] = 0.f; }
+    if (qvalid) {
+        const T* qp = base + (row0 + qi) * p.ld + h * DK;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) q[d] = (float)qp[d];
+    }
+    float m = -INFINITY, l = 0.f;
+
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        const int cnt = min(64, len - k0);
+        __syncthreads();
+        if (lane < cnt) {
+            const T* kp = base + (row0 + k0 + lane) * p.ld + p.C + h * DK;
+            const T* vp = kp + p.C;
+#pragma unroll
+            for (int d = 0; d < DK; ++d) {
+                Ks[lane * KP + d] = (float)kp[d];
+                Vs[lane * KP + d] = (float)vp[d];
+            }
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < cnt; j0 += 8) {
+            float sc[8];
+            float cm = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                float a = 0.f;
+                if (j < cnt) {
+                    const float4* kr = reinterpret_cast<const float4*>(Ks + j * KP);
+#pragma unroll
+                    for (int d4 = 0; d4 < DK / 4; ++d4) {
+                        const float4 kv = kr[d4];
+                        a = fmaf(q[4 * d4 + 0], kv.x, a);
+                        a = fmaf(q[4 * d4 + 1], kv.y, a);
+                        a = fmaf(q[4 * d4 + 2], kv.z, a);
+                        a = fmaf(q[4 * d4 + 3], kv.w, a);
+                    }
+                    a *= scale;
+                } else {
+                    a = -INFINITY;
+                }
+                sc[jj] = a;
+                cm = fmaxf(cm, a);
+            }
+            const float mn = fmaxf(m, cm);
+            const float alpha = expf(m - mn);   // m = -inf on the first chunk -> 0
+            l *= alpha;
+#pragma unroll
+            for (int d = 0; d < DK; ++d) o[d] *= alpha;
+            m = mn;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                if (j < cnt) {
+                    const float pj = expf(sc[jj] - m);
+                    l += pj;
+                    const float4* vr = reinterpret_cast<const float4*>(Vs + j * KP);
+#pragma unroll
+                    for (int d4 = 0; d4 < DK / 4; ++d4) {
+                        const float4 vv = vr[d4];
+                        o[4 * d4 + 0] = fmaf(pj, vv.x, o[4 * d4 + 0]);
+                        o[4 * d4 + 1] = fmaf(pj, vv.y, o[4 * d4 + 1]);
+                        o[4 * d4 + 2] = fmaf(pj, vv.z, o[4 * d4 + 2]);
+                        o[4 * d4 + 3] = fmaf(pj, vv.w, o[4 * d4 + 3]);
+                    }
+                }
+            }
+        }
+    }
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        T* op = reinterpret_cast<T*>(p.out) + (row0 + qi) * p.ldo + h * DK;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) op[d] = (T)(o[d] * inv);
+    }
+}
+void launch_attention(const AttnParams& p, hipStream_t s) {
+    dim3 grid((p.max_len + 63) / 64, p.heads, p.B);
+    if (p.dtype == DT_F16) hipLaunchKernelGGL((attention_kernel<_Float16, 48>), grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((attention_kernel<float, 48>), grid, dim3(64), 0, s, p);
+}
+
+// ------------------------------------------------------------------ conditioning vector
+// reference model_open_source.py:109-111: the speaker/style/content part of embed_projection1's input is
+// constant over time, so its contribution (plus the bias) is one vector per utterance.
+__global__ __launch_bounds__(256) void cond_vector_kernel(const int64_t* speaker, const float* style, const float* content,
+                                                          const float* spk_emb, const float* Wcond, const float* bias, float* u,
+                                                          int C, int bert) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const int ncond = C + 2 * bert;
+    const float* w = Wcond + (long)c * ncond;
+    const float* se = spk_emb + speaker[b] * C;
+    float a = 0.f;
+    for (int i = lane; i < C; i += 64) a = fmaf(w[i], se[i], a);
+    for (int i = lane; i < bert; i += 64) a = fmaf(w[C + i], style[(long)b * bert + i], a);
+    for (int i = lane; i < bert; i += 64) a = fmaf(w[C + bert + i], content[(long)b * bert + i], a);
+    a = wave_sum(a);
+    if (lane == 0) u[(long)b * C + c] = a + bias[c];
+}
+void launch_cond_vector(const int64_t* speaker, const float* style, const float* content, const float* spk_emb, const float* Wcond,
+                        const float* bias, float* u, int B, int C, int bert, hipStream_t s) {
+    hipLaunchKernelGGL(cond_vector_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, speaker, style, content, spk_emb, Wcond, bias, u,
+                       C, bert);
+}
+
+// ------------------------------------------------------------------ pitch / energy embedding add
+// reference model_open_source.py:131-134: Conv1d(1 -> C, k, pad (k-1)/2) on the predicted scalar tracks.
+// wp / we are packed [k][C].
+__global__ __launch_bounds__(256) void var_embed_add_kernel(const float* x, const float* pitch, const float* energy, const float* wp,
+                                                            const float* bp, const float* we, const float* be,
+                                                            const uint8_t* row_valid, float* out, int rows, int C, int k) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bool valid = row_valid[row] != 0;
+    const int half = (k - 1) / 2;
+    for (int c = lane * 2; c < C; c += 128) {
+        float2 r = make_float2(0.f, 0.f);
+        if (valid) {
+            const float2 xv = *reinterpret_cast<const float2*>(x + (long)row * C + c);
+            const float2 b0 = *reinterpret_cast<const float2*>(bp + c);
+            const float2 b1 = *reinterpret_cast<const float2*>(be + c);
+            float2 ap = b0, ae = b1;
+            for (int t = 0; t < k; ++t) {
+                const float pv = pitch[row + t - half], evv = energy[row + t - half];
+                const float2 w0 = *reinterpret_cast<const float2*>(wp + (long)t * C + c);
+                const float2 w1 = *reinterpret_cast<const float2*>(we + (long)t * C + c);
+                ap.x = fmaf(w0.x, pv, ap.x); ap.y = fmaf(w0.y, pv, ap.y);
+                ae.x = fmaf(w1.x, evv, ae.x); ae.y = fmaf(w1.y, evv, ae.y);
+            }
+            r.x = xv.x + ap.x + ae.x;
+            r.y = xv.y + ap.y + ae.y;
+        }
+        *reinterpret_cast<float2*>(out + (long)row * C + c) = r;
+    }
+}
+void launch_var_embed_add(const float* x, const float* pitch, const float* energy, const float* wp, const float* bp, const float* we,
+                          const float* be, const uint8_t* row_valid, float* out, int rows, int C, int k, hipStream_t s) {
+    hipLaunchKernelGGL(var_embed_add_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, pitch, energy, wp, bp, we, be, row_valid, out,
+                       rows, C, k);
+}
+
+// ------------------------------------------------------------------ durations + prefix sum
+// reference modules/variance.py:47-51: d = clamp(round(exp(x) - 1), 0) (round-half-even);
+// modules/alignment.py:183-202: ds*alpha, all-zero guard, mel_len = int(sum), c = cumsum(ds) - ds/2.
+// One 256-thread block per utterance; inclusive scan = wave shuffle scan + cross-wave carry in LDS.
+__global__ __launch_bounds__(256) void durations_kernel(const float* log_d, const int32_t* tok_off, const int32_t* tok_len,
+                                                        float alpha, const int64_t* forced, const int32_t* cu, int64_t* dur_packed,
+                                                        float* logd_packed, float* centre_rows, int32_t* mel_len) {
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    __shared__ int total_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int off = tok_off[b], n = tok_len[b], c0 = cu[b];
+    // pass 1: integer durations + total
+    int local = 0;
+    for (int j = tid; j < n; j += 256) {
+        const float ld = log_d[off + j];
+        long d;
+        if (forced) d = forced[c0 + j];
+        else d = (long)fmaxf(rintf(expf(ld) - 1.0f), 0.0f);
+        dur_packed[c0 + j] = d;
+        logd_packed[c0 + j] = ld;
+        local += (int)d;
+    }
+    int ws = local;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ws += __shfl_xor(ws, o);
+    if (lane == 0) wsum[w] = ws;
+    __syncthreads();
+    if (tid == 0) { total_s = wsum[0] + wsum[1] + wsum[2] + wsum[3]; carry_s = 0; }
+    __syncthreads();
+    const bool all_zero = (total_s == 0);   // alignment.py:187-191 (per utterance == B=1 semantics)
+    if (alpha == 1.0f) {
+        // integer inclusive scan, chunk of 256 tokens at a time (exact; fp32 cumsum of integers is exact too)
+        for (int base = 0; base < n; base += 256) {
+            const int j = base + tid;
+            int d = 0;
+            if (j < n) d = all_zero ? 1 : (int)dur_packed[c0 + j];
+            int x = d;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(x, o);
+                if (lane >= o) x += y;
+            }
+            if (lane == 63) wsum[w] = x;
+            __syncthreads();
+            int pre = carry_s;
+            for (int i = 0; i < w; ++i) pre += wsum[i];
+            const int incl = pre + x;
+            if (j < n) centre_rows[off + j] = (float)incl - (float)d / 2.0f;
+            __syncthreads();
+            if (tid == 255) carry_s = incl;
+            __syncthreads();
+        }
+        if (tid == 0) mel_len[b] = all_zero ? n : total_s;
+    } else {
+        // general alpha: sequential fp32 cumsum like torch.cumsum on CPU
+        if (tid == 0) {
+            float cs = 0.f;
+            for (int j = 0; j < n; ++j) {
+                const float d = all_zero ? 1.0f : (float)dur_packed[c0 + j] * alpha;
+                cs += d;
+                centre_rows[off + j] = cs - d / 2.0f;
+            }
+            mel_len[b] = (int)cs;
+        }
+    }
+}
+void launch_durations(const float* log_d, const int32_t* tok_off, const int32_t* tok_len, int B, float alpha, const int64_t* forced,
+                      const int32_t* cu, int64_t* dur_packed, float* logd_packed, float* centre_rows, int32_t* mel_len,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s, log_d, tok_off, tok_len, alpha, forced, cu, dur_packed,
+                       logd_packed, centre_rows, mel_len);
+}
+
+// ------------------------------------------------------------------ Gaussian upsampling
+// reference modules/alignment.py:204-210: p = softmax_j(-delta (t - c_j)^2); out[t] = sum_j p_j x[j]
+// followed by the decoder's x + alpha * pe[t] (modules/encoder.py:257-261).  One wave per frame.
+__global__ __launch_bounds__(256) void gauss_upsample_kernel(const float* xvar, const float* centre, const int32_t* tok_off,
+                                                             const int32_t* tok_len, const int32_t* row_seq, const int32_t* row_pos,
+                                                             const float* pe, float pe_alpha, float delta, float* out, float* tap,
+                                                             int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = row_seq[row];
+    float* o = out + (long)row * C;
+    if (b < 0) {
+        for (int c = lane * 2; c < C; c += 128) {
+            *reinterpret_cast<float2*>(o + c) = make_float2(0.f, 0.f);
+            if (tap) *reinterpret_cast<float2*>(tap + (long)row * C + c) = make_float2(0.f, 0.f);
+        }
+        return;
+    }
+    const int t = row_pos[row];
+    const int off = tok_off[b], n = tok_len[b];
+    const float tf = (float)t;
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) {
+        const float dd = tf - centre[off + j];
+        mx = fmaxf(mx, -1.0f * delta * (dd * dd));
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    int jlo = n, jhi = -1;
+    for (int j = lane; j < n; j += 64) {
+        const float dd = tf - centre[off + j];
+        const float e = expf(-1.0f * delta * (dd * dd) - mx);
+        sum += e;
+        if (e > 0.f) { jlo = min(jlo, j); jhi = max(jhi, j); }
+    }
+    sum = wave_sum(sum);
+    jlo = wave_min_i(jlo);
+    jhi = wave_max_i(jhi);
+    float2 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = make_float2(0.f, 0.f);
+    for (int j = jlo; j <= jhi; ++j) {
+        const float dd = tf - centre[off + j];
+        const float pj = expf(-1.0f * delta * (dd * dd) - mx) / sum;
+        const float* xr = xvar + (long)(off + j) * C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = i * 128 + lane * 2;
+            if (c < C) {
+                const float2 xv = *reinterpret_cast<const float2*>(xr + c);
+                acc[i].x = fmaf(pj, xv.x, acc[i].x);
+                acc[i].y = fmaf(pj, xv.y, acc[i].y);
+            }
+        }
+    }
+    const float* pr = pe + (long)t * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 128 + lane * 2;
+        if (c < C) {
+            if (tap) *reinterpret_cast<float2*>(tap + (long)row * C + c) = acc[i];
+            const float2 pv = *reinterpret_cast<const float2*>(pr + c);
+            *reinterpret_cast<float2*>(o + c) = make_float2(acc[i].x + pe_alpha * pv.x, acc[i].y + pe_alpha * pv.y);
+        }
+    }
+}
+void launch_gauss_upsample(const float* xvar, const float* centre_rows, const int32_t* tok_off, const int32_t* tok_len,
+                           const int32_t* frm_row_seq, const int32_t* frm_row_pos, const float* pe, float pe_alpha, float delta,
+                           float* out, float* tap_out, int rows, int C, hipStream_t s) {
+    hipLaunchKernelGGL(gauss_upsample_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, xvar, centre_rows, tok_off, tok_len, frm_row_seq,
+                       frm_row_pos, pe, pe_alpha, delta, out, tap_out, rows, C);
+}
+
+// ------------------------------------------------------------------ mel (B x (n_mels, T)) -> channels-last rows
+__global__ __launch_bounds__(256) void mel_to_rows_kernel(const void* mel, int is_f16, const int64_t* mel_elem_off,
+                                                          const int32_t* row_seq, const int32_t* row_pos, const int32_t* mel_len,
+                                                          __half* out, int rows, int n_mels, int ldo) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)rows * ldo) return;
+    const int row = (int)(idx / ldo), c = (int)(idx % ldo);
+    const int b = row_seq[row];
+    float v = 0.f;
+    if (b >= 0 && c < n_mels) {
+        const long e = mel_elem_off[b] + (long)c * mel_len[b] + row_pos[row];
+        v = is_f16 ? __half2float(reinterpret_cast<const __half*>(mel)[e]) : reinterpret_cast<const float*>(mel)[e];
+    }
+    out[idx] = __float2half_rn(v);
+}
+void launch_mel_to_rows(const void* mel, int is_f16, const int64_t* mel_elem_off, const int32_t* frm_row_seq,
+                        const int32_t* frm_row_pos, const int32_t* mel_len, void* out16, int rows, int n_mels, int ldo,
+                        hipStream_t s) {
+    const long n = (long)rows * ldo;
+    hipLaunchKernelGGL(mel_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel, is_f16, mel_elem_off, frm_row_seq,
+                       frm_row_pos, mel_len, reinterpret_cast<__half*>(out16), rows, n_mels, ldo);
+}
+
+// ------------------------------------------------------------------ conv_post + tanh
+// reference models/hifigan/models.py:127-129: leaky_relu(0.01) [fused into the producer] -> Conv1d(C->1,k7,p3) -> tanh.
+// Block = 256 output samples; the (256 + k - 1) x C fp16 input rows are staged in LDS (80-B pitch).
+template <int C>
+__global__ __launch_bounds__(256) void conv_post_kernel(const __half* x, int ldx, const float* w, float bias, int k,
+                                                        const uint8_t* row_valid, int valid_shift, float* wav_rows, int rows) {
+    constexpr int PITCH = C * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char xs[(256 + 16) * PITCH];
+    __shared__ float ws[16 * C];
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * 256;
+    const int half = (k - 1) / 2;
+    const int nrows = 256 + k - 1;
+    constexpr int CPR = C * 2 / 16;   // 16-B chunks per row
+    for (int c = tid; c < nrows * CPR; c += 256) {
+        const int r = c / CPR, part = c % CPR;
+        *reinterpret_cast<uint4*>(xs + r * PITCH + part * 16) =
+            *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((r0 + r - half) * ldx) * 2 + part * 16);
+    }
+    for (int i = tid; i < k * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long row = r0 + tid;
+    if (row >= rows) return;
+    float a = bias;
+    for (int t = 0; t < k; ++t) {
+        const char* xr = xs + (tid + t) * PITCH;
+#pragma unroll
+        for (int part = 0; part < CPR; ++part) {
+            const uint4 v = *reinterpret_cast<const uint4*>(xr + part * 16);
+            const __half2* h = reinterpret_cast<const __half2*>(&v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                a = fmaf(f.x, ws[t * C + part * 8 + e * 2], a);
+                a = fmaf(f.y, ws[t * C + part * 8 + e * 2 + 1], a);
+            }
+        }
+    }
+    const bool valid = row_valid[row >> valid_shift] != 0;
+    wav_rows[row] = valid ? tanhf(a) : 0.f;
+}
+void launch_conv_post(const void* x16, int ldx, const float* w, float bias, int k, const uint8_t* row_valid, int valid_shift,
+                      float* wav_rows, int rows, int C, hipStream_t s) {
+    const int grid = (rows + 255) / 256;
+    if (C == 32)
+        hipLaunchKernelGGL((conv_post_kernel<32>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const __half*>(x16), ldx, w, bias, k,
+                           row_valid, valid_shift, wav_rows, rows);
+}
+
+// ------------------------------------------------------------------ packing helpers
+__global__ __launch_bounds__(256) void pack_rows_kernel(const void* src, int dtype, int ld, int C, const int64_t* seq_row_off,
+                                                        const int64_t* seq_out_off, const int32_t* seq_rows, float* dst) {
+    const int b = blockIdx.y;
+    const long n = (long)seq_rows[b] * C;
+    const long src0 = seq_row_off[b], dst0 = seq_out_off[b] * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / C, c = i % C;
+        float v;
+        if (dtype == DT_F16) v = __half2float(reinterpret_cast<const __half*>(src)[(src0 + r) * ld + c]);
+        else v = reinterpret_cast<const float*>(src)[(src0 + r) * ld + c];
+        dst[dst0 + i] = v;
+    }
+}
+void launch_pack_rows(const void* src, int dtype, int ld, int C, const int64_t* seq_row_off, const int64_t* seq_out_off,
+                      const int32_t* seq_rows, int B, int64_t max_rows, float* dst, hipStream_t s) {
+    long blocks = (max_rows * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks, B), dim3(256), 0, s, src, dtype, ld, C, seq_row_off, seq_out_off,
+                       seq_rows, dst);
+}
+
+// reference inference_am_vocoder_joint.py:130-131: (wav * 32768.0).astype('int16') -> C cast (truncate, wrap)
+__global__ __launch_bounds__(256) void wav_to_i16_kernel(const float* wav, int16_t* out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = (int16_t)(int32_t)(wav[i] * 32768.0f);
+}
+void launch_wav_to_i16(const float* wav, int16_t* out, int64_t n, hipStream_t s) {
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wav_to_i16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, wav, out, (long)n);
+}
+
+void launch_fill_zero(void* p, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, 0, bytes, s); }
+
+}  // namespace ev

@@ -1,0 +1,199 @@
+"""Object wrapper over the libevhip.so handle: numpy / raw-pointer in, numpy out.  No torch needed."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .config import EVShapes
+
+
+class EVError(RuntimeError):
+    pass
+
+
+def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages: bool = False) -> _ffi.ev_config:
+    cfg = _ffi.ev_config()
+    _ffi.lib().ev_default_config(C.byref(cfg))
+    for f in ("n_vocab", "n_speaker", "n_mels", "hidden", "heads", "enc_layers", "dec_layers", "ffn_kernel", "bert_dim",
+              "dur_layers", "pitch_layers", "energy_layers", "var_kernel", "var_embed_kernel", "up_init_ch"):
+        setattr(cfg, f, int(getattr(shapes, f)))
+    cfg.n_up = len(shapes.up_rates)
+    for i, (u, k) in enumerate(zip(shapes.up_rates, shapes.up_kernels)):
+        cfg.up_rates[i], cfg.up_kernels[i] = int(u), int(k)
+    cfg.n_rb = len(shapes.rb_kernels)
+    cfg.n_rb_dils = len(shapes.rb_dils[0])
+    for j, k in enumerate(shapes.rb_kernels):
+        cfg.rb_kernels[j] = int(k)
+        for d, v in enumerate(shapes.rb_dils[j]):
+            cfg.rb_dils[j][d] = int(v)
+    cfg.sample_rate = int(shapes.sr)
+    cfg.decoder_precision = {"f16": _ffi.EV_PREC_F16, "f32": _ffi.EV_PREC_F32}[decoder_precision]
+    cfg.keep_stages = 1 if keep_stages else 0
+    return cfg
+
+
+class EVEngine:
+    """One handle = one GPU + one stream + one workspace (include/evhip.h).  Not thread-safe."""
+
+    def __init__(self, shapes: Optional[EVShapes] = None, device_id: int = 0, decoder_precision: str = "f16",
+                 keep_stages: bool = False):
+        self.shapes = shapes or EVShapes()
+        self._lib = _ffi.lib()
+        self._h = C.c_void_p()
+        cfg = make_ev_config(self.shapes, decoder_precision, keep_stages)
+        if self._lib.ev_create(device_id, C.byref(cfg), C.byref(self._h)) != 0:
+            raise EVError(self._lib.ev_last_error(None).decode())
+        self.device_id = device_id
+        self._blob_keepalive = None
+        self.last: Optional[_ffi.ev_result] = None
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ev_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EVError(self._lib.ev_last_error(self._h).decode())
+
+    def set_stream(self, hip_stream_ptr: int):
+        self._check(self._lib.ev_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.ev_set_profiling(self._h, 1 if on else 0))
+
+    # -- weights
+    def load_blob(self, blob: bytes, manifest_json: Optional[str] = None):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._check(self._lib.ev_load_weights(self._h, C.cast(buf, C.c_void_p), len(blob),
+                                              manifest_json.encode() if manifest_json else None))
+
+    def load_blob_device(self, dptr: int, nbytes: int, keepalive=None):
+        """Borrow a blob that already lives in device memory (e.g. after an RCCL broadcast)."""
+        self._blob_keepalive = keepalive
+        self._check(self._lib.ev_load_weights_device(self._h, C.c_void_p(dptr), nbytes, None))
+
+    # -- raw calls (host or device pointers)
+    def synthesize_raw(self, B: int, ling_ptr: int, cu_seqlens: np.ndarray, speaker_ptr: int, style_ptr: int,
+                       content_ptr: int, alpha: float = 1.0, flags: int = 0) -> _ffi.ev_result:
+        cu = np.ascontiguousarray(cu_seqlens, np.int32)
+        res = _ffi.ev_result()
+        self._check(self._lib.ev_synthesize(self._h, B, C.c_void_p(ling_ptr), cu.ctypes.data_as(C.c_void_p),
+                                            C.c_void_p(speaker_ptr), C.c_void_p(style_ptr), C.c_void_p(content_ptr),
+                                            C.c_float(alpha), flags, C.byref(res)))
+        self.last = res
+        return res
+
+    def vocoder_raw(self, B: int, mel_ptr: int, mel_is_f16: bool, mel_lens: np.ndarray, flags: int = 0) -> _ffi.ev_result:
+        ml = np.ascontiguousarray(mel_lens, np.int32)
+        res = _ffi.ev_result()
+        self._check(self._lib.ev_vocoder(self._h, B, C.c_void_p(mel_ptr), 1 if mel_is_f16 else 0,
+                                         ml.ctypes.data_as(C.c_void_p), flags, C.byref(res)))
+        self.last = res
+        return res
+
+    def set_forced_durations(self, durations: np.ndarray):
+        d = np.ascontiguousarray(durations, np.int64)
+        self._check(self._lib.ev_set_forced_durations(self._h, d.ctypes.data_as(C.c_void_p), d.size))
+
+    # -- helpers
+    def d2h(self, dev_ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            self._check(self._lib.ev_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), out.nbytes))
+        return out
+
+    def result_to_numpy(self, res: _ffi.ev_result, want_int16: bool = False) -> Dict[str, object]:
+        B = res.batch
+        mel_lens = np.array([res.mel_lens[b] for b in range(B)], np.int32)
+        mel_offs = np.array([res.mel_offsets[b] for b in range(B + 1)], np.int64)
+        up = self.shapes.upsample_factor
+        out: Dict[str, object] = dict(mel_lens=mel_lens, mel_offsets=mel_offs)
+        if res.wav:
+            out["wav"] = self.d2h(res.wav, (res.total_samples,), np.float32)
+            out["wav_list"] = [out["wav"][mel_offs[b] * up:mel_offs[b + 1] * up] for b in range(B)]
+        if want_int16 and res.wav_i16:
+            out["wav_i16"] = self.d2h(res.wav_i16, (res.total_samples,), np.int16)
+        if res.mel:
+            out["mel"] = self.d2h(res.mel, (res.total_frames, self.shapes.n_mels), np.float32)
+            out["mel_list"] = [out["mel"][mel_offs[b]:mel_offs[b + 1]] for b in range(B)]
+        if res.durations:
+            out["durations"] = self.d2h(res.durations, (res.total_tokens,), np.int64)
+            out["log_durations"] = self.d2h(res.log_durations, (res.total_tokens,), np.float32)
+            out["pitch"] = self.d2h(res.pitch, (res.total_tokens,), np.float32)
+            out["energy"] = self.d2h(res.energy, (res.total_tokens,), np.float32)
+        return out
+
+    # -- numpy convenience API
+    def synthesize(self, utts: Sequence[dict], alpha: float = 1.0, want_int16: bool = False, vocoder: bool = True,
+                   forced_durations: Optional[np.ndarray] = None) -> Dict[str, object]:
+        """utts: dicts with ling (N,) int64, speaker int, style (768,), content (768,) -- the four fields the
+        reference builds per input line (inference_am_vocoder_joint.py:113-119)."""
+        B = len(utts)
+        ling = np.ascontiguousarray(np.concatenate([np.asarray(u["ling"], np.int64) for u in utts]))
+        cu = np.zeros(B + 1, np.int32)
+        cu[1:] = np.cumsum([len(u["ling"]) for u in utts])
+        spk = np.ascontiguousarray([int(u["speaker"]) for u in utts], np.int64)
+        style = np.ascontiguousarray(np.stack([np.asarray(u["style"], np.float32) for u in utts]))
+        content = np.ascontiguousarray(np.stack([np.asarray(u["content"], np.float32) for u in utts]))
+        flags = 0
+        if want_int16:
+            flags |= _ffi.EV_FLAG_WANT_INT16
+        if not vocoder:
+            flags |= _ffi.EV_FLAG_NO_VOCODER
+        if forced_durations is not None:
+            self.set_forced_durations(forced_durations)
+            flags |= _ffi.EV_FLAG_FORCED_DURATIONS
+        res = self.synthesize_raw(B, ling.ctypes.data, cu, spk.ctypes.data, style.ctypes.data, content.ctypes.data, alpha, flags)
+        out = self.result_to_numpy(res, want_int16)
+        out["cu_seqlens"] = cu
+        return out
+
+    def vocoder(self, mels: Sequence[np.ndarray], want_int16: bool = False) -> Dict[str, object]:
+        """mels: list of (n_mels, T_b) arrays (the reference's (B,80,T) layout per utterance), fp32 or fp16."""
+        is16 = mels[0].dtype == np.float16
+        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(m, mels[0].dtype).ravel() for m in mels]))
+        lens = np.array([m.shape[1] for m in mels], np.int32)
+        flags = _ffi.EV_FLAG_WANT_INT16 if want_int16 else 0
+        res = self.vocoder_raw(len(mels), flat.ctypes.data, is16, lens, flags)
+        return self.result_to_numpy(res, want_int16)
+
+    def get_stage(self, name: str) -> np.ndarray:
+        """Stage tap of the last call (SURVEY.md Appendix C names; needs keep_stages=True): (rows, C) fp32."""
+        need = self._lib.ev_get_stage(self._h, name.encode(), None, 0)
+        if need < 0:
+            raise EVError(self._lib.ev_last_error(self._h).decode())
+        if name in ("dur", "mel_len"):
+            out = np.empty(need // 8, np.int64)
+        else:
+            out = np.empty(need // 4, np.float32)
+        got = self._lib.ev_get_stage(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes)
+        if got < 0:
+            raise EVError(self._lib.ev_last_error(self._h).decode())
+        return out
+
+    def timings(self) -> Dict[str, float]:
+        out = {}
+        ms = C.c_float()
+        for name in ("total", "am", "encoder", "variance", "decoder", "vocoder"):
+            if self._lib.ev_get_timing(self._h, name.encode(), C.byref(ms)) == 0:
+                out[name] = float(ms.value)
+        return out
+
+    def kernel_stats(self) -> List[dict]:
+        out = []
+        st = _ffi.ev_kernel_stat()
+        for i in range(self._lib.ev_kernel_stat_count(self._h)):
+            self._lib.ev_get_kernel_stat(self._h, i, C.byref(st))
+            out.append(dict(name=st.name.decode(), launches=st.launches, ms=float(st.ms), flops=float(st.flops), bytes=float(st.bytes)))
+        return out

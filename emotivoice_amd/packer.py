@@ -1,0 +1,218 @@
+"""Weight packer: reference ``JETSGenerator`` state dict -> one flat blob for libevhip.so.
+
+Replaces what ``load_state_dict`` + the per-forward weight-norm recompute do in the reference
+(inference_am_vocoder_joint.py:72-73; models/hifigan/models.py:10-14 -- the joint path never calls
+``remove_weight_norm`` so the reference re-evaluates ``g*v/||v||`` for 50 convs on every forward,
+SURVEY.md section 6).  Here weight-norm is folded once, weights are laid out as the GEMM kernels read
+them ([N][taps][K], K contiguous), q/k/v are fused, ``embed_projection1`` is split into its
+time-varying 384 columns and the per-utterance conditioning columns, ConvTranspose1d becomes a
+3-tap polyphase conv, and the sinusoid table (not in the state dict, modules/encoder.py:213-237) is
+regenerated.  The blob is what one RCCL broadcast ships to the other ranks.
+
+Blob layout (little endian):
+  "EVW1\\0\\0\\0\\0" | u32 count | u32 0 | count x entry | data
+  entry = char name[64] | u32 dtype (0 f16, 1 f32) | u32 ndim | u64 dims[4] | u64 offset | u64 nbytes
+Tensor data is 256-byte aligned.
+"""
+from __future__ import annotations
+
+import json
+import struct
+from typing import Dict, Tuple
+
+import numpy as np
+
+MEL_PAD = 96
+DT_F16, DT_F32 = 0, 1
+_ENTRY = struct.Struct("<64sII4QQQ")
+
+
+def _np(x) -> np.ndarray:
+    if isinstance(x, np.ndarray):
+        return x
+    if hasattr(x, "detach"):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def _fold_weight_norm(sd, prefix) -> np.ndarray:
+    """w = g * v / ||v||, norm over all dims but 0 (torch weight_norm default dim=0).  Accepts the
+    torch>=2.1 parametrization keys, the legacy weight_g/weight_v keys of the released checkpoints
+    (trained with torch 1.11 / 2.0.1, reference Dockerfile:6, cog.yaml:14) and plain weights."""
+    for gk, vk in ((".parametrizations.weight.original0", ".parametrizations.weight.original1"),
+                   (".weight_g", ".weight_v")):
+        if prefix + gk in sd:
+            g = _np(sd[prefix + gk]).astype(np.float64)
+            v = _np(sd[prefix + vk]).astype(np.float64)
+            nrm = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(1)).reshape((-1,) + (1,) * (v.ndim - 1))
+            return (g * v / nrm).astype(np.float32)
+    return _np(sd[prefix + ".weight"]).astype(np.float32)
+
+
+def _conv_to_gemm(w: np.ndarray, k_pad: int | None = None) -> np.ndarray:
+    """Conv1d weight [C_out, C_in, k] -> [C_out][k][C_in] (optionally zero-padding C_in)."""
+    w = np.ascontiguousarray(np.transpose(w, (0, 2, 1)))
+    if k_pad is not None and k_pad != w.shape[2]:
+        out = np.zeros((w.shape[0], w.shape[1], k_pad), w.dtype)
+        out[:, :, : w.shape[2]] = w
+        w = out
+    return w
+
+
+def _convT_to_gemm(wt: np.ndarray, stride: int) -> np.ndarray:
+    """ConvTranspose1d weight [C_in, C_out, K=2s], padding s/2 -> 3-tap conv [s*C_out][3][C_in].
+
+    out[t*s + p, co] = sum_ci sum_tau x[t + tau - 1, ci] * Wt[ci, co, kk(p, tau)] with q = p + s/2:
+      tau=0 (x[t-1]): kk = q + s   (only if q <  s)
+      tau=1 (x[t]  ): kk = q
+      tau=2 (x[t+1]): kk = q - s   (only if q >= s)
+    (from n = i*s - pad + kk of torch.nn.ConvTranspose1d; models/hifigan/models.py:99-103)."""
+    cin, cout, K = wt.shape
+    s = stride
+    assert K == 2 * s and s % 2 == 0
+    out = np.zeros((s * cout, 3, cin), np.float32)
+    for p in range(s):
+        q = p + s // 2
+        blk = out[p * cout:(p + 1) * cout]
+        if q < s:
+            blk[:, 0, :] = wt[:, :, q + s].T
+        blk[:, 1, :] = wt[:, :, q].T
+        if q >= s:
+            blk[:, 2, :] = wt[:, :, q - s].T
+    return out
+
+
+def sinusoid_table(length: int, d: int) -> np.ndarray:
+    """modules/encoder.py:216-237, evaluated with torch fp32 ops like the reference does."""
+    import math
+
+    import torch
+
+    pos = torch.arange(0, length, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(length, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.numpy()
+
+
+class _Blob:
+    def __init__(self):
+        self.items = []
+
+    def add(self, name: str, arr: np.ndarray, dtype: int):
+        arr = np.ascontiguousarray(arr, dtype=np.float16 if dtype == DT_F16 else np.float32)
+        assert arr.ndim <= 4 and len(name) < 64, name
+        self.items.append((name, arr, dtype))
+
+    def both(self, name: str, arr: np.ndarray):
+        self.add(name + "32", arr, DT_F32)
+        self.add(name + "16", arr, DT_F16)
+
+    def finish(self) -> Tuple[bytes, dict]:
+        n = len(self.items)
+        off = 16 + n * _ENTRY.size
+        table, manifest = [], {}
+        chunks = []
+        for name, arr, dtype in self.items:
+            off = (off + 255) // 256 * 256
+            dims = list(arr.shape) + [0] * (4 - arr.ndim)
+            if arr.ndim == 0:
+                dims = [1, 0, 0, 0]
+            table.append(_ENTRY.pack(name.encode(), dtype, max(arr.ndim, 1), *dims, off, arr.nbytes))
+            manifest[name] = dict(dtype="f16" if dtype == DT_F16 else "f32", shape=list(arr.shape), offset=off,
+                                  nbytes=arr.nbytes)
+            chunks.append((off, arr))
+            off += arr.nbytes
+        buf = bytearray(off)
+        buf[0:8] = b"EVW1\0\0\0\0"
+        struct.pack_into("<II", buf, 8, n, 0)
+        pos = 16
+        for t in table:
+            buf[pos:pos + len(t)] = t
+            pos += len(t)
+        for o, arr in chunks:
+            buf[o:o + arr.nbytes] = arr.tobytes()
+        return bytes(buf), manifest
+
+
+def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> Tuple[bytes, str]:
+    """Pack a reference ``JETSGenerator`` state dict (``am.*`` / ``generator.*`` keys, optionally with a
+    DDP ``module.`` prefix) into (blob, manifest_json)."""
+    from .config import EVShapes
+
+    s = shapes or EVShapes()
+    if any(k.startswith("module.") for k in sd):
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    H = s.hidden
+    b = _Blob()
+    f32 = lambda k: _np(sd[k]).astype(np.float32)  # noqa: E731
+
+    b.add("pe", sinusoid_table(pe_len, H), DT_F32)
+    b.add("tok_emb", f32("am.src_word_emb.weight"), DT_F32)
+    b.add("spk_emb", f32("am.spk_tokenizer.weight"), DT_F32)
+    for short, pre, nl in (("enc", "am.encoder", s.enc_layers), ("dec", "am.decoder", s.dec_layers)):
+        b.add(f"{short}.alpha", f32(f"{pre}.embed.0.alpha").reshape(1), DT_F32)
+        for i in range(nl):
+            p = f"{pre}.encoders.{i}"
+            wq = [f32(f"{p}.self_attn.linear_{n}.weight") for n in "qkv"]
+            bq = [f32(f"{p}.self_attn.linear_{n}.bias") for n in "qkv"]
+            b.both(f"{short}.{i}.qkv.w", np.concatenate(wq, 0)[:, None, :])
+            b.add(f"{short}.{i}.qkv.b", np.concatenate(bq, 0), DT_F32)
+            b.both(f"{short}.{i}.out.w", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
+            b.add(f"{short}.{i}.out.b", f32(f"{p}.self_attn.linear_out.bias"), DT_F32)
+            b.both(f"{short}.{i}.ffn1.w", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))
+            b.add(f"{short}.{i}.ffn1.b", f32(f"{p}.feed_forward.w_1.bias"), DT_F32)
+            b.both(f"{short}.{i}.ffn2.w", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
+            b.add(f"{short}.{i}.ffn2.b", f32(f"{p}.feed_forward.w_2.bias"), DT_F32)
+            for j in (1, 2):
+                b.add(f"{short}.{i}.ln{j}.g", f32(f"{p}.norm{j}.weight"), DT_F32)
+                b.add(f"{short}.{i}.ln{j}.b", f32(f"{p}.norm{j}.bias"), DT_F32)
+        b.add(f"{short}.after.g", f32(f"{pre}.after_norm.weight"), DT_F32)
+        b.add(f"{short}.after.b", f32(f"{pre}.after_norm.bias"), DT_F32)
+
+    wp = f32("am.embed_projection1.weight")              # [H, H + H + 2*bert], column order x|spk|style|content
+    b.add("proj.w32", wp[:, None, :H], DT_F32)
+    b.add("proj.wcond", wp[:, H:], DT_F32)
+    b.add("proj.b", f32("am.embed_projection1.bias"), DT_F32)
+    for short, pre, nl in (("dur", "am.duration_predictor", s.dur_layers), ("pitch", "am.pitch_predictor", s.pitch_layers),
+                           ("energy", "am.energy_predictor", s.energy_layers)):
+        for i in range(nl):
+            b.add(f"{short}.{i}.conv.w32", _conv_to_gemm(f32(f"{pre}.conv.{i}.0.weight")), DT_F32)
+            b.add(f"{short}.{i}.conv.b", f32(f"{pre}.conv.{i}.0.bias"), DT_F32)
+            b.add(f"{short}.{i}.ln.g", f32(f"{pre}.conv.{i}.2.weight"), DT_F32)
+            b.add(f"{short}.{i}.ln.b", f32(f"{pre}.conv.{i}.2.bias"), DT_F32)
+        b.add(f"{short}.lin.w", f32(f"{pre}.linear.weight").reshape(H), DT_F32)
+        b.add(f"{short}.lin.b", f32(f"{pre}.linear.bias").reshape(1), DT_F32)
+    for short, pre in (("pitch_emb", "am.pitch_embed.0"), ("energy_emb", "am.energy_embed.0")):
+        b.add(f"{short}.w", np.ascontiguousarray(f32(f"{pre}.weight")[:, 0, :].T), DT_F32)   # [k][C]
+        b.add(f"{short}.b", f32(f"{pre}.bias"), DT_F32)
+    wm = np.zeros((MEL_PAD, 1, H), np.float32)
+    wm[: s.n_mels, 0] = f32("am.to_mel.weight")
+    bm = np.zeros(MEL_PAD, np.float32)
+    bm[: s.n_mels] = f32("am.to_mel.bias")
+    b.both("to_mel.w", wm)
+    b.add("to_mel.b", bm, DT_F32)
+
+    g = "generator"
+    b.add("voc.pre.w16", _conv_to_gemm(_fold_weight_norm(sd, f"{g}.conv_pre"), MEL_PAD), DT_F16)
+    b.add("voc.pre.b", f32(f"{g}.conv_pre.bias"), DT_F32)
+    ch = s.up_init_ch
+    nk = len(s.rb_kernels)
+    for i, (u, k) in enumerate(zip(s.up_rates, s.up_kernels)):
+        assert k == 2 * u, "polyphase packing needs kernel = 2*stride"
+        b.add(f"voc.up{i}.w16", _convT_to_gemm(_fold_weight_norm(sd, f"{g}.ups.{i}"), u), DT_F16)
+        b.add(f"voc.up{i}.b", np.tile(f32(f"{g}.ups.{i}.bias"), u), DT_F32)
+        ch //= 2
+        for j in range(nk):
+            r = i * nk + j
+            for d in range(len(s.rb_dils[j])):
+                for grp, short in (("convs1", "c1"), ("convs2", "c2")):
+                    pre = f"{g}.resblocks.{r}.{grp}.{d}"
+                    b.add(f"voc.rb{r}.{short}.{d}.w16", _conv_to_gemm(_fold_weight_norm(sd, pre)), DT_F16)
+                    b.add(f"voc.rb{r}.{short}.{d}.b", f32(pre + ".bias"), DT_F32)
+    wpost = _fold_weight_norm(sd, f"{g}.conv_post")     # [1, C, 7]
+    b.add("voc.post.w", np.ascontiguousarray(wpost[0].T), DT_F32)   # [7][C]
+    b.add("voc.post.b", f32(f"{g}.conv_post.bias").reshape(1), DT_F32)
+    blob, manifest = b.finish()
+    return blob, json.dumps(manifest)

@@ -1,0 +1,166 @@
+/*
+ * evhip.h -- C ABI of libevhip.so: the MI355X-native (gfx950) EmotiVoice inference hot path.
+ *
+ * The reference has no FFI/plugin interface for this path; its boundary is the Python object
+ * protocol of JETSGenerator (reference models/prompt_tts_modified/jets.py:26-71).  Each entry
+ * point below replaces one piece of that protocol:
+ *
+ *   ev_create            <- JETSGenerator.__init__(config) + .to(device)      (jets.py:27-47,
+ *                           inference_am_vocoder_joint.py:70)
+ *   ev_load_weights[_device] <- .load_state_dict(ckpt['generator'])           (inference_am_vocoder_joint.py:72-73)
+ *   ev_synthesize        <- JETSGenerator.forward, inference branch           (jets.py:50-71 ->
+ *                           model_open_source.py:102-163 -> models/hifigan/models.py:115-131)
+ *   ev_vocoder           <- HiFiGANGenerator.forward on pre-computed mels     (models/hifigan/models.py:115-131)
+ *   ev_get_stage         <- register_forward_hook taps used by the parity tests
+ *   ev_last_error        <- Python exceptions (no exceptions cross the ABI)
+ *
+ * Conventions: 0 = OK, negative = error (message via ev_last_error).  A handle owns one device,
+ * one HIP stream and one workspace arena; it is NOT thread-safe (the reference is single-threaded
+ * per process as well).  Inputs are borrowed for the duration of a call.  Outputs are owned by
+ * the handle and stay valid until the next ev_synthesize / ev_vocoder / ev_destroy on it.
+ * No torch types appear anywhere in this interface: plain pointers and sizes only.
+ */
+#ifndef EVHIP_H_
+#define EVHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EV_ABI_VERSION 1
+
+typedef struct ev_handle ev_handle;
+
+/* Mirrors reference config/joint/config.yaml:36-94 (+ n_vocab/n_speaker patched in by the
+ * callers, inference_am_vocoder_joint.py:57-58).  Use ev_default_config() and override. */
+typedef struct ev_config {
+    int32_t abi_version;        /* EV_ABI_VERSION */
+    int32_t n_vocab;            /* 502   */
+    int32_t n_speaker;          /* 2014  */
+    int32_t n_mels;             /* 80    */
+    int32_t hidden;             /* 384 (encoder/decoder/variance hidden) */
+    int32_t heads;              /* 8     */
+    int32_t enc_layers;         /* 4     */
+    int32_t dec_layers;         /* 4     */
+    int32_t ffn_kernel;         /* 3     */
+    int32_t bert_dim;           /* 768   */
+    int32_t dur_layers;         /* 2     */
+    int32_t pitch_layers;       /* 3     */
+    int32_t energy_layers;      /* 2     */
+    int32_t var_kernel;         /* 3     */
+    int32_t var_embed_kernel;   /* 9     */
+    int32_t n_up;               /* 4     */
+    int32_t up_rates[8];        /* 8,8,2,2 */
+    int32_t up_kernels[8];      /* 16,16,4,4 */
+    int32_t up_init_ch;         /* 512   */
+    int32_t n_rb;               /* 3     */
+    int32_t rb_kernels[8];      /* 3,7,11 */
+    int32_t rb_dils[8][4];      /* {1,3,5} x3 */
+    int32_t n_rb_dils;          /* 3     */
+    int32_t sample_rate;        /* 16000 */
+    /* engine options (not in the reference) */
+    int32_t decoder_precision;  /* EV_PREC_F16 (default) or EV_PREC_F32 (strict parity mode) */
+    int32_t keep_stages;        /* !=0: keep every Appendix-C stage tap retrievable by ev_get_stage */
+    int32_t reserved[8];
+} ev_config;
+
+enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1 };
+
+/* flags for ev_synthesize / ev_vocoder */
+enum {
+    EV_FLAG_DEVICE_INPUTS = 1,  /* all input pointers are device pointers (zero-copy from a torch-ROCm tensor) */
+    EV_FLAG_NO_VOCODER = 2,     /* acoustic model only (mel out) */
+    EV_FLAG_WANT_INT16 = 4,     /* also produce the caller epilogue wav*32768 -> int16 (inference_am_vocoder_joint.py:130-131) */
+    EV_FLAG_FORCED_DURATIONS = 8 /* teacher-forced durations (test mode): use result-independent durations passed via ev_set_forced_durations */
+};
+
+/* Result of one call.  All pointers are DEVICE pointers owned by the handle.
+ * Packed layouts: utterance b occupies [mel_offsets[b], mel_offsets[b]+mel_lens[b]) rows of mel and
+ * 256x that range of wav; tokens are packed exactly like the `ling` input (cu_seqlens). */
+typedef struct ev_result {
+    int32_t batch;
+    int32_t total_tokens;
+    int64_t total_frames;           /* sum of mel_lens */
+    int64_t total_samples;          /* total_frames * prod(up_rates) */
+    const float*   wav;             /* (total_samples,) fp32 in [-1,1]        = wav_predictions   */
+    const int16_t* wav_i16;         /* (total_samples,) or NULL                                   */
+    const float*   mel;             /* (total_frames, n_mels) fp32 row-major  = dec_outputs       */
+    const int64_t* durations;       /* (total_tokens,)  int64                 = log_duration_predictions (inference) */
+    const float*   log_durations;   /* (total_tokens,)  fp32, pre-round (test tap)                */
+    const float*   pitch;           /* (total_tokens,)  fp32                  = pitch_predictions  */
+    const float*   energy;          /* (total_tokens,)  fp32                  = energy_predictions */
+    const int32_t* mel_lens;        /* (batch,) HOST pointer                                      */
+    const int64_t* mel_offsets;     /* (batch+1,) HOST pointer: exclusive prefix sum of mel_lens  */
+} ev_result;
+
+void ev_default_config(ev_config* cfg);
+
+int ev_create(int device_id, const ev_config* cfg, ev_handle** out);
+void ev_destroy(ev_handle* h);
+const char* ev_last_error(ev_handle* h);   /* h may be NULL: returns the last creation error */
+
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of the
+ * handle's own stream.  Pass NULL to go back to the internal stream. */
+int ev_set_stream(ev_handle* h, void* hip_stream);
+
+/* Packed weight blob produced by emotivoice_amd/packer.py (self-describing; manifest_json is an
+ * optional human-readable copy of the table and may be NULL).  Host pointer: copied to the device.
+ * Device pointer variant (after an RCCL broadcast): borrowed, must outlive the handle. */
+int ev_load_weights(ev_handle* h, const void* blob, size_t nbytes, const char* manifest_json);
+int ev_load_weights_device(ev_handle* h, const void* dptr, size_t nbytes, const char* manifest_json);
+
+/* JETSGenerator.forward (inference): B utterances, tokens packed back to back.
+ *   ling      (cu_seqlens[B],) int64 phoneme ids            = inputs_ling (unpadded)
+ *   cu_seqlens(B+1,) int32 HOST pointer, cu_seqlens[0] = 0   = input_lengths as prefix sums
+ *   speaker   (B,) int64                                     = inputs_speaker
+ *   style     (B, bert_dim) fp32                             = inputs_style_embedding
+ *   content   (B, bert_dim) fp32                             = inputs_content_embedding
+ *   alpha     duration scale (reference call sites pass 1.0)
+ * Every utterance is evaluated with the reference's B = 1 semantics (zero halo at sequence edges,
+ * attention restricted to its own tokens / frames). */
+int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu_seqlens,
+                  const int64_t* speaker, const float* style, const float* content,
+                  float alpha, uint32_t flags, ev_result* out);
+
+/* Durations for EV_FLAG_FORCED_DURATIONS: (total_tokens,) int64 HOST pointer, copied. */
+int ev_set_forced_durations(ev_handle* h, const int64_t* durations, int64_t n);
+
+/* HiFi-GAN generator only.  mel: B tensors packed back to back, each (n_mels, mel_lens[b]) row-major
+ * (the reference's (B,80,T) layout per utterance), fp32 or fp16 (mel_is_f16). mel_lens: HOST pointer. */
+int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32_t* mel_lens,
+               uint32_t flags, ev_result* out);
+
+/* Copy a named stage tap (SURVEY.md Appendix C names) of the LAST call to host memory as fp32
+ * (integer taps as int64), in the packed utterance-major layout (rows x channels, valid rows only).
+ * Returns the number of bytes written, or a negative error (e.g. cap too small, unknown name,
+ * keep_stages disabled).  With host_dst == NULL returns the required size. */
+int64_t ev_get_stage(ev_handle* h, const char* name, void* host_dst, size_t cap);
+
+/* Convenience for callers without a HIP runtime binding (numpy/ctypes): synchronous device -> host copy
+ * of one of the result pointers. */
+int ev_memcpy_d2h(ev_handle* h, void* host_dst, const void* dev_src, size_t nbytes);
+
+/* Timing of the last call, measured with hipEvents on the handle's stream (ms).  Names: "total",
+ * "am", "encoder", "variance", "decoder", "vocoder".  Enabled by ev_set_profiling(h, 1). */
+int ev_set_profiling(ev_handle* h, int enable);
+int ev_get_timing(ev_handle* h, const char* name, float* ms);
+
+/* Per-kernel-family accounting of the last call (profiling enabled): number of launches, summed
+ * hipEvent duration and algorithmic FLOPs / bytes.  idx in [0, ev_kernel_stat_count). */
+typedef struct ev_kernel_stat {
+    char name[48];
+    int32_t launches;
+    float ms;
+    double flops;
+    double bytes;
+} ev_kernel_stat;
+int ev_kernel_stat_count(ev_handle* h);
+int ev_get_kernel_stat(ev_handle* h, int idx, ev_kernel_stat* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVHIP_H_ */

@@ -1,0 +1,54 @@
+/*
+ * evhip_ops.h -- per-kernel entry points of libevhip.so used by the parity tests (tests/test_gpu_ops.py).
+ * They launch one gfx950 kernel on caller-provided DEVICE pointers and are not needed by an integrator;
+ * the drop-in boundary is include/evhip.h.  Each op cites the reference op it is checked against.
+ */
+#ifndef EVHIP_OPS_H_
+#define EVHIP_OPS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Implicit-GEMM conv / linear (emotivoice_amd/csrc/ev_gemm.hip).  Checked against torch.nn.functional
+ * linear / conv1d / conv_transpose1d, i.e. the ops behind reference modules/encoder.py:50-52,72-109,
+ * modules/variance.py:41-46 and models/hifigan/models.py:50-57,116-128.
+ *   out[m,n] = post( scale * ( act( sum_{tap,k} pro(A[m+(tap-center)*dil,k]) * W[n][tap][k] + bias[n] )
+ *                               + seq_bias[row_seq[m]][n] + res[m,n] ) + acc32[m,n] ), invalid rows -> 0
+ * Field order and types mirror ev::ConvGemmParams exactly. */
+typedef struct ev_conv_gemm_desc {
+    int dtype;                 /* 0: fp16 operands (MFMA 16x16x32 f16), 1: fp32 operands (MFMA 16x16x4 f32) */
+    const void* A; int lda;
+    const void* W;
+    const float* bias;
+    int M, N, K, taps, dil, center;
+    const uint8_t* row_valid; int valid_shift;
+    const int32_t* row_seq; const float* seq_bias; int ld_seq_bias;
+    int act; float act_slope;  /* 0 none, 1 relu, 2 gelu(erf), 3 leaky_relu, 4 tanh */
+    int pro_lrelu; float pro_slope;
+    const void* res; int res_dtype; int ldres;
+    float out_scale;
+    const float* acc32; int ldacc;
+    int post_lrelu; float post_slope;
+    void* out16; float* out32; int ldo;
+    int out32_before_post;
+} ev_conv_gemm_desc;
+
+int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* hip_stream);
+
+/* LayerNorm(eps) over channels, optional fused Linear(C,1) head (reference modules/encoder.py:112-127,
+ * modules/variance.py:29-33,46). */
+int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
+                    const uint8_t* row_valid, void* out16, float* out32, const float* dot_w, float dot_b,
+                    float* dot_out, void* hip_stream);
+
+/* Multi-head self-attention restricted to each utterance's rows (reference modules/encoder.py:72-109). */
+int ev_op_attention(const void* qkv, int is_f16, int C, int heads, const int32_t* seq_off, const int32_t* seq_len,
+                    int B, int max_len, void* out, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVHIP_OPS_H_ */

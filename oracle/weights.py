@@ -1,207 +1,8 @@
-"""Seeded synthetic weights + inputs for the hot path (TEST INFRASTRUCTURE ONLY).
+"""Synthetic checkpoint / input generators used by the oracle-side tests.
 
-The released checkpoints (g_00140000, SimBERT) are downloads that are not in
-the container (reference predict.py:30-55), so parity is defined on seeded
-synthetic weights.  This module builds a state dict with exactly the 422 keys /
-shapes the reference ``JETSGenerator`` produces under torch >= 2.1
-(``parametrizations.weight.original0/1`` = weight-norm g / v; SURVEY.md
-Appendix A), drawn from numpy's PCG64 so they are bit-identical on every box.
-
-Distributions follow the reference constructor
-(models/prompt_tts_modified/modules/initialize.py:11-49 -> xavier_uniform for
-dim>1, embeddings N(0,1); models/hifigan/models.py default Conv1d init), then a
-"trained-like" perturbation is applied so that every code path is exercised by
-the parity tests: non-zero biases, LayerNorm gamma != 1 / beta != 0, positional
-alpha != 1, weight-norm g != ||v||.
-
-Duration-head calibration:
-  dur_mode="bench"  : linear.weight = 0, bias = log 5  -> exactly 4 frames/phoneme
-  dur_mode="parity" : linear.weight *= 0.3, bias = log 5 -> durations ~2..7 (round/cumsum exercised)
-  dur_mode="stress" : linear.weight *= 1.0, bias = log 3 -> wide spread incl. zeros
+The generator itself is plain data synthesis (numpy PCG64) and lives in the product package
+(emotivoice_amd/synthetic.py) because bench.py needs it without touching the oracle; the oracle
+re-exports it so tests can keep importing everything checker-related from ``oracle``.
 """
-from __future__ import annotations
-
-import math
-from dataclasses import dataclass, field
-from typing import Dict, List, Tuple
-
-import numpy as np
-
-
-@dataclass
-class EVShapes:
-    """Model hyper-parameters (values of reference config/joint/config.yaml:36-94
-    plus n_vocab / n_speaker from config/joint/config.py:56,60)."""
-
-    n_vocab: int = 502
-    n_speaker: int = 2014
-    n_mels: int = 80
-    hidden: int = 384           # encoder_n_hidden == decoder_n_hidden == variance_n_hidden
-    heads: int = 8
-    enc_layers: int = 4
-    dec_layers: int = 4
-    ffn_kernel: int = 3         # encoder/decoder_kernel_size_conv_mod
-    bert_dim: int = 768
-    dur_layers: int = 2
-    pitch_layers: int = 3       # variance_n_layers
-    energy_layers: int = 2      # hard-coded model_open_source.py:70-76
-    var_kernel: int = 3
-    var_embed_kernel: int = 9
-    up_rates: Tuple[int, ...] = (8, 8, 2, 2)
-    up_kernels: Tuple[int, ...] = (16, 16, 4, 4)
-    up_init_ch: int = 512
-    rb_kernels: Tuple[int, ...] = (3, 7, 11)
-    rb_dils: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
-    sr: int = 16000
-    hop: int = 256
-
-
-def _xavier(rng, shape):
-    # torch.nn.init.xavier_uniform_: fan_in = shape[1]*rf, fan_out = shape[0]*rf
-    rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
-    fan_in, fan_out = shape[1] * rf, shape[0] * rf
-    bound = math.sqrt(6.0 / (fan_in + fan_out))
-    return rng.uniform(-bound, bound, size=shape).astype(np.float32)
-
-
-def _kaiming_default(rng, shape):
-    # torch Conv1d default: kaiming_uniform(a=sqrt(5)) -> U(+-1/sqrt(fan_in)), fan_in = shape[1]*rf
-    rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
-    bound = 1.0 / math.sqrt(shape[1] * rf)
-    return rng.uniform(-bound, bound, size=shape).astype(np.float32), bound
-
-
-def synth_state_dict(seed: int = 0, dur_mode: str = "parity", shapes: EVShapes | None = None,
-                     perturb: bool = True, voc_gain: float = 1.2, rb_gain: float = 2.2) -> Dict[str, np.ndarray]:
-    """Return {reference state-dict key: float32 ndarray} (422 entries)."""
-    s = shapes or EVShapes()
-    rng = np.random.default_rng(seed)
-    H = s.hidden
-    sd: Dict[str, np.ndarray] = {}
-
-    def bias(n, scale=0.02):
-        if perturb:
-            return (rng.standard_normal(n) * scale).astype(np.float32)
-        return np.zeros(n, np.float32)
-
-    def ln(prefix):
-        if perturb:
-            sd[prefix + ".weight"] = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
-            sd[prefix + ".bias"] = (0.05 * rng.standard_normal(H)).astype(np.float32)
-        else:
-            sd[prefix + ".weight"] = np.ones(H, np.float32)
-            sd[prefix + ".bias"] = np.zeros(H, np.float32)
-
-    def stack(prefix, n_layers):
-        sd[f"{prefix}.embed.0.alpha"] = np.float32(1.0 + (0.137 if perturb else 0.0)) * np.ones((), np.float32)
-        for i in range(n_layers):
-            p = f"{prefix}.encoders.{i}"
-            for nm in ("q", "k", "v", "out"):
-                sd[f"{p}.self_attn.linear_{nm}.weight"] = _xavier(rng, (H, H))
-                sd[f"{p}.self_attn.linear_{nm}.bias"] = bias(H)
-            sd[f"{p}.feed_forward.w_1.weight"] = _xavier(rng, (4 * H, H, s.ffn_kernel))
-            sd[f"{p}.feed_forward.w_1.bias"] = bias(4 * H)
-            sd[f"{p}.feed_forward.w_2.weight"] = _xavier(rng, (H, 4 * H, s.ffn_kernel))
-            sd[f"{p}.feed_forward.w_2.bias"] = bias(H)
-            ln(f"{p}.norm1")
-            ln(f"{p}.norm2")
-        ln(f"{prefix}.after_norm")
-
-    def predictor(prefix, n_layers):
-        for i in range(n_layers):
-            sd[f"{prefix}.conv.{i}.0.weight"] = _xavier(rng, (H, H, s.var_kernel))
-            sd[f"{prefix}.conv.{i}.0.bias"] = bias(H)
-            ln(f"{prefix}.conv.{i}.2")
-        sd[f"{prefix}.linear.weight"] = _xavier(rng, (1, H))
-        sd[f"{prefix}.linear.bias"] = bias(1)
-
-    stack("am.encoder", s.enc_layers)
-    stack("am.decoder", s.dec_layers)
-    predictor("am.duration_predictor", s.dur_layers)
-    predictor("am.pitch_predictor", s.pitch_layers)
-    sd["am.pitch_embed.0.weight"] = _xavier(rng, (H, 1, s.var_embed_kernel))
-    sd["am.pitch_embed.0.bias"] = bias(H)
-    predictor("am.energy_predictor", s.energy_layers)
-    sd["am.energy_embed.0.weight"] = _xavier(rng, (H, 1, s.var_embed_kernel))
-    sd["am.energy_embed.0.bias"] = bias(H)
-    # alignment module: present in the checkpoint, unused at inference
-    for nm, shp in (("t_conv1", (H, H, 3)), ("t_conv2", (H, H, 1)), ("f_conv1", (H, s.n_mels, 3)),
-                    ("f_conv2", (H, H, 3)), ("f_conv3", (H, H, 1))):
-        sd[f"am.alignment_module.{nm}.weight"] = _xavier(rng, shp)
-        sd[f"am.alignment_module.{nm}.bias"] = np.zeros(H, np.float32)
-    sd["am.to_mel.weight"] = _xavier(rng, (s.n_mels, H))
-    sd["am.to_mel.bias"] = bias(s.n_mels, 0.05)
-    sd["am.spk_tokenizer.weight"] = rng.standard_normal((s.n_speaker, H)).astype(np.float32)
-    sd["am.src_word_emb.weight"] = rng.standard_normal((s.n_vocab, H)).astype(np.float32)
-    sd["am.embed_projection1.weight"] = _xavier(rng, (H, 2 * H + 2 * s.bert_dim))
-    sd["am.embed_projection1.bias"] = bias(H)
-
-    # duration head calibration
-    w = sd["am.duration_predictor.linear.weight"]
-    if dur_mode == "bench":
-        w[...] = 0.0
-        sd["am.duration_predictor.linear.bias"][...] = math.log(5.0)
-    elif dur_mode == "parity":
-        w *= 0.3
-        sd["am.duration_predictor.linear.bias"][...] = math.log(5.0)
-    elif dur_mode == "stress":
-        sd["am.duration_predictor.linear.bias"][...] = math.log(3.0)
-    elif dur_mode != "raw":
-        raise ValueError(dur_mode)
-
-    # HiFi-GAN generator (weight-norm parametrised convs)
-    def wn_conv(prefix, shape, gain):
-        v, bound = _kaiming_default(rng, shape)
-        nrm = np.sqrt((v.astype(np.float64) ** 2).reshape(shape[0], -1).sum(1)).astype(np.float32)
-        g = nrm * gain
-        if perturb:
-            g = g * rng.uniform(0.85, 1.15, size=g.shape).astype(np.float32)
-        sd[f"{prefix}.bias"] = None  # placeholder to keep key order bias,g,v like the reference
-        sd[f"{prefix}.parametrizations.weight.original0"] = g.reshape(shape[0], 1, 1).astype(np.float32)
-        sd[f"{prefix}.parametrizations.weight.original1"] = v
-        return bound
-
-    def conv_bias(prefix, n, bound):
-        sd[f"{prefix}.bias"] = rng.uniform(-bound, bound, size=n).astype(np.float32)
-
-    b = wn_conv("generator.conv_pre", (s.up_init_ch, s.n_mels, 7), voc_gain)
-    conv_bias("generator.conv_pre", s.up_init_ch, b)
-    ch = s.up_init_ch
-    for i, (u, k) in enumerate(zip(s.up_rates, s.up_kernels)):
-        # ConvTranspose1d weight layout [C_in, C_out, K]; weight-norm dim 0 = per INPUT channel
-        b = wn_conv(f"generator.ups.{i}", (ch, ch // 2, k), voc_gain * 2.0)
-        conv_bias(f"generator.ups.{i}", ch // 2, b)
-        ch //= 2
-    ch = s.up_init_ch
-    for i in range(len(s.up_rates)):
-        ch //= 2
-        for j, k in enumerate(s.rb_kernels):
-            r = i * len(s.rb_kernels) + j
-            for grp in ("convs1", "convs2"):
-                for d in range(len(s.rb_dils[j])):
-                    p = f"generator.resblocks.{r}.{grp}.{d}"
-                    b = wn_conv(p, (ch, ch, k), rb_gain)
-                    conv_bias(p, ch, b)
-    b = wn_conv("generator.conv_post", (1, ch, 7), voc_gain)
-    conv_bias("generator.conv_post", 1, b)
-    assert all(v is not None for v in sd.values())
-    return sd
-
-
-def synth_inputs(seed: int, lengths: List[int], speakers: List[int] | None = None,
-                 shapes: EVShapes | None = None, bounded: bool = True):
-    """Seeded synthetic utterances: list of dicts with ling (N,) int64, speaker int,
-    style (768,), content (768,) float32.  ``bounded`` -> tanh(randn), matching the
-    (-1,1) range of real BERT pooler outputs."""
-    s = shapes or EVShapes()
-    rng = np.random.default_rng(seed)
-    out = []
-    for i, n in enumerate(lengths):
-        ling = rng.integers(0, s.n_vocab, size=n, dtype=np.int64)
-        style = rng.standard_normal(s.bert_dim).astype(np.float32)
-        content = rng.standard_normal(s.bert_dim).astype(np.float32)
-        if bounded:
-            style, content = np.tanh(style), np.tanh(content)
-        spk = 0 if speakers is None else int(speakers[i])
-        out.append(dict(ling=ling, speaker=spk, style=style, content=content))
-    return out
+from emotivoice_amd.config import EVShapes  # noqa: F401
+from emotivoice_amd.synthetic import synth_inputs, synth_state_dict  # noqa: F401

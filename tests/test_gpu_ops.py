@@ -1,0 +1,245 @@
+"""Per-kernel parity tests (MI355X): each gfx950 kernel, launched through the C ABI entry points of
+include/evhip_ops.h, against the plain fp32 torch op it replaces."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from emotivoice_amd import _ffi
+    return _ffi.lib()
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+PAD = 64
+
+
+def _padded(rows, cols, dtype, fill=None):
+    """[PAD + rows + PAD, cols] device tensor; returns (full, view of the logical rows)."""
+    full = torch.randn(rows + 2 * PAD, cols, device="cuda", dtype=torch.float32).to(dtype)
+    return full, full[PAD:PAD + rows]
+
+
+def _run_conv(lib, x_view, w_torch, bias, *, dtype, taps, dil, center, row_valid=None, valid_shift=0, act=0, act_slope=0.0,
+              pro_slope=None, res=None, scale=1.0, acc32=None, post_slope=None, seq_bias=None, row_seq=None,
+              want16=True, want32=True, before_post=False):
+    from emotivoice_amd import _ffi
+    M, K = x_view.shape
+    N = w_torch.shape[0]
+    tdt = torch.float16 if dtype == 0 else torch.float32
+    wg = w_torch.permute(0, 2, 1).contiguous().to(tdt)           # [N][taps][K]
+    d = _ffi.ev_conv_gemm_desc()
+    d.dtype = dtype
+    d.A, d.lda = x_view.data_ptr(), x_view.stride(0)
+    d.W = wg.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.M, d.N, d.K, d.taps, d.dil, d.center = M, N, K, taps, dil, center
+    if row_valid is not None:
+        d.row_valid, d.valid_shift = row_valid.data_ptr(), valid_shift
+    if seq_bias is not None:
+        d.row_seq, d.seq_bias, d.ld_seq_bias = row_seq.data_ptr(), seq_bias.data_ptr(), seq_bias.stride(0)
+    d.act, d.act_slope = act, act_slope
+    if pro_slope is not None:
+        d.pro_lrelu, d.pro_slope = 1, pro_slope
+    if res is not None:
+        d.res, d.res_dtype, d.ldres = res.data_ptr(), (0 if res.dtype == torch.float16 else 1), res.stride(0)
+    d.out_scale = scale
+    if acc32 is not None:
+        d.acc32, d.ldacc = acc32.data_ptr(), acc32.stride(0)
+    if post_slope is not None:
+        d.post_lrelu, d.post_slope = 1, post_slope
+    out16 = torch.full((M, N), 7.0, device="cuda", dtype=torch.float16) if want16 else None
+    out32 = torch.full((M, N), 7.0, device="cuda", dtype=torch.float32) if want32 else None
+    d.out16 = out16.data_ptr() if want16 else None
+    d.out32 = out32.data_ptr() if want32 else None
+    d.ldo = N
+    d.out32_before_post = 1 if before_post else 0
+    torch.cuda.synchronize()
+    rc = lib.ev_op_conv_gemm(C.byref(d), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out16, out32
+
+
+def _ref_conv(x, w, bias, dil, center, taps):
+    """x [M,K] fp32 (already rounded to the operand dtype), w [N,K,taps] -> [M,N] fp32 on CPU."""
+    xc = x.float().cpu().t().unsqueeze(0)
+    y = F.conv1d(xc, w.float().cpu(), bias.float().cpu() if bias is not None else None, dilation=dil, padding=center * dil)
+    # "same" geometry only when the conv is centred
+    assert center * 2 == taps - 1
+    return y.squeeze(0).t()
+
+
+def _lrelu(x, s):
+    return torch.where(x > 0, x, x * s)
+
+
+CONV_CASES = [
+    # name, dtype, M, K, N, taps, dil
+    ("f16_linear_384", 0, 512, 384, 384, 1, 1),
+    ("f16_ffn1_k3", 0, 256, 384, 1536, 3, 1),
+    ("f16_ffn2_k3", 0, 256, 1536, 384, 3, 1),
+    ("f16_c32_k11_d5", 0, 1024, 32, 32, 11, 5),
+    ("f16_c64_k7_d3", 0, 512, 64, 64, 7, 3),
+    ("f16_c128_k3_d1", 0, 512, 128, 128, 3, 1),
+    ("f16_c256_k11_d1", 0, 256, 256, 256, 11, 1),
+    ("f16_n96", 0, 256, 384, 96, 1, 1),
+    ("f32_linear_384", 1, 256, 384, 384, 1, 1),
+    ("f32_qkv", 1, 256, 384, 1152, 1, 1),
+    ("f32_conv_k3", 1, 512, 384, 384, 3, 1),
+    ("f32_n32_k7", 1, 256, 32, 32, 7, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_gemm_plain(lib, case):
+    name, dtype, M, K, N, taps, dil = case
+    torch.manual_seed(hash(name) % 1000)
+    tdt = torch.float16 if dtype == 0 else torch.float32
+    full, x = _padded(M, K, tdt)
+    w = (torch.randn(N, K, taps, device="cuda") / math.sqrt(K * taps)).to(tdt)
+    bias = torch.randn(N, device="cuda")
+    center = (taps - 1) // 2
+    # zero halo: the rows outside [0, M) that the conv reads must be zero for the torch 'same' reference
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    o16, o32 = _run_conv(lib, x, w, bias, dtype=dtype, taps=taps, dil=dil, center=center)
+    ref = _ref_conv(x, w, bias, dil, center, taps)
+    tol32 = 2e-5 if dtype == 0 else 1e-5
+    assert _rel(o32.cpu(), ref) < tol32, name
+    assert _rel(o16.float().cpu(), ref) < 6e-4, name
+    # transpose detection: the error must not be explained by a swapped output layout
+    assert o32.shape == (M, N)
+
+
+def test_conv_gemm_full_epilogue(lib):
+    """ResBlock-style call: leaky-relu prologue, bias, residual, scale, fp32 accumulate-in, post leaky-relu,
+    row mask with shift, out32 taken before the post activation (models/hifigan/models.py:50-57,121-127)."""
+    torch.manual_seed(3)
+    M, C_, taps, dil = 1024, 64, 7, 3
+    full, x = _padded(M, C_, torch.float16)
+    valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
+    valid[:4] = 0
+    valid[60:70] = 0
+    valid[-4:] = 0
+    vrow = valid.repeat_interleave(8).bool()
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x[~vrow] = 0
+    w = (torch.randn(C_, C_, taps, device="cuda") / math.sqrt(C_ * taps)).half()
+    bias = torch.randn(C_, device="cuda")
+    res = torch.randn(M, C_, device="cuda").half()
+    acc = torch.randn(M, C_, device="cuda")
+    o16, o32 = _run_conv(lib, x, w, bias, dtype=0, taps=taps, dil=dil, center=3, row_valid=valid, valid_shift=3,
+                         pro_slope=0.1, res=res, scale=1.0 / 3.0, acc32=acc, post_slope=0.01, before_post=True)
+    xin = _lrelu(x.float(), 0.1).half().float()     # prologue is applied in fp16 on the staged tile
+    ref = _ref_conv(xin, w, bias, dil, 3, taps)
+    ref = (ref + res.float().cpu()) * (1.0 / 3.0) + acc.cpu()
+    ref_post = _lrelu(ref, 0.01)
+    m = vrow.cpu()
+    ref[~m] = 0
+    ref_post[~m] = 0
+    assert _rel(o32.cpu(), ref) < 2e-5
+    assert _rel(o16.float().cpu(), ref_post) < 6e-4
+    assert float(o32[~vrow].abs().max()) == 0.0 and float(o16[~vrow].float().abs().max()) == 0.0
+
+
+def test_conv_gemm_activations_and_seq_bias(lib):
+    torch.manual_seed(4)
+    M, K, N = 256, 384, 384
+    full, x = _padded(M, K, torch.float32)
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    w = torch.randn(N, K, 1, device="cuda") / math.sqrt(K)
+    bias = torch.randn(N, device="cuda")
+    row_seq = torch.randint(0, 3, (M,), device="cuda", dtype=torch.int32)
+    sb = torch.randn(3, N, device="cuda")
+    for act, fn in ((1, torch.relu), (2, F.gelu), (4, torch.tanh), (3, lambda t: _lrelu(t, 0.1))):
+        _, o32 = _run_conv(lib, x, w, bias, dtype=1, taps=1, dil=1, center=0, act=act, act_slope=0.1, seq_bias=sb,
+                           row_seq=row_seq, want16=False)
+        ref = fn(_ref_conv(x, w, bias, 1, 0, 1)) + sb.cpu()[row_seq.cpu().long()]
+        assert _rel(o32.cpu(), ref) < 1e-5, act
+
+
+@pytest.mark.parametrize("cin,s", [(64, 2), (128, 2), (256, 8), (512, 8)])
+def test_conv_transpose_polyphase(lib, cin, s):
+    """ConvTranspose1d(k = 2s, stride s, pad s/2) as the packed 3-tap conv (models/hifigan/models.py:99-103,119)."""
+    from emotivoice_amd.packer import _convT_to_gemm
+    torch.manual_seed(5)
+    cout, M = cin // 2, 256
+    full, x = _padded(M, cin, torch.float16)
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    wt = (torch.randn(cin, cout, 2 * s) / math.sqrt(cin * 2)).half().float()
+    bias = torch.randn(cout)
+    wg = torch.from_numpy(_convT_to_gemm(wt.numpy(), s)).cuda()              # [s*cout][3][cin]
+    w_as_conv = wg.permute(0, 2, 1).contiguous()                             # torch layout [N, K, taps]
+    o16, o32 = _run_conv(lib, x, w_as_conv, bias.repeat(s).cuda(), dtype=0, taps=3, dil=1, center=1)
+    got = o32.cpu().reshape(M * s, cout)
+    ref = F.conv_transpose1d(x.float().cpu().t().unsqueeze(0), wt, bias, stride=s, padding=s // 2).squeeze(0).t()
+    assert ref.shape == got.shape
+    assert _rel(got, ref) < 2e-5
+
+
+def test_layernorm_and_head(lib):
+    torch.manual_seed(6)
+    rows, Cc = 300, 384
+    x = torch.randn(rows, Cc, device="cuda") * 3 + 0.5
+    g, b = torch.randn(Cc, device="cuda"), torch.randn(Cc, device="cuda")
+    w = torch.randn(Cc, device="cuda")
+    valid = torch.ones(rows, dtype=torch.uint8, device="cuda")
+    valid[7] = 0
+    o16 = torch.empty(rows, Cc, device="cuda", dtype=torch.float16)
+    o32 = torch.empty(rows, Cc, device="cuda")
+    dot = torch.empty(rows, device="cuda")
+    rc = lib.ev_op_layernorm(x.data_ptr(), rows, Cc, g.data_ptr(), b.data_ptr(), 1e-12, valid.data_ptr(), o16.data_ptr(),
+                             o32.data_ptr(), w.data_ptr(), 0.25, dot.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.cpu(), (Cc,), g.cpu(), b.cpu(), 1e-12)
+    ref[7] = 0
+    refdot = ref @ w.cpu() + 0.25
+    refdot[7] = 0
+    assert _rel(o32.cpu(), ref) < 2e-6
+    assert _rel(o16.float().cpu(), ref) < 5e-4
+    assert _rel(dot.cpu(), refdot) < 5e-6
+
+
+@pytest.mark.parametrize("is_f16", [0, 1])
+def test_attention_ragged(lib, is_f16):
+    """Attention restricted to each utterance's rows == per-utterance B=1 attention (modules/encoder.py:72-109)."""
+    torch.manual_seed(7)
+    Cc, H = 384, 8
+    lens = [70, 1, 130, 64]
+    offs, rows = [], 4
+    for n in lens:
+        offs.append(rows)
+        rows += n + 4
+    dt = torch.float16 if is_f16 else torch.float32
+    qkv = torch.randn(rows, 3 * Cc, device="cuda").to(dt)
+    out = torch.zeros(rows, Cc, device="cuda", dtype=dt)
+    so = torch.tensor(offs, dtype=torch.int32, device="cuda")
+    sl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    rc = lib.ev_op_attention(qkv.data_ptr(), is_f16, Cc, H, so.data_ptr(), sl.data_ptr(), len(lens), max(lens), out.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for o, n in zip(offs, lens):
+        blk = qkv[o:o + n].float().cpu()
+        q, k, v = [t.view(n, H, 48).transpose(0, 1) for t in blk.split(Cc, dim=1)]
+        att = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(48), dim=-1) @ v
+        ref = att.transpose(0, 1).reshape(n, Cc)
+        assert _rel(out[o:o + n].float().cpu(), ref) < (6e-4 if is_f16 else 2e-6)

@@ -1,0 +1,244 @@
+"""End-to-end parity on MI355X: libevhip.so (through the C ABI) vs the CPU oracle and the committed
+golden fixtures (outputs of the reference itself).
+
+Tolerances (BASELINE.json north_star): mel / waveform <= 1e-3 relative L2 against the fp32 reference;
+durations / mel lengths bit-exact.  Stage taps of the fp32 token-rate path are held to 1e-4.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOL_OUT = 1e-3          # north_star tolerance for mel and waveform
+TOL_F32_TAP = 1e-4      # fp32 token-rate taps
+REPORT = {}
+
+
+def _report(key, val):
+    REPORT[key] = val
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def rel_l2_ac(a, b):
+    """relative L2 after removing the mean of the reference (DC-insensitive, stricter for wav)."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    mu = b.mean()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b - mu), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return True
+
+
+_CACHE = {}
+
+
+def _weights(mode):
+    from oracle import synth_state_dict
+    from oracle.jets_oracle import to_torch_sd
+    from emotivoice_amd.packer import pack_state_dict
+    if mode not in _CACHE:
+        sd = synth_state_dict(0, mode)
+        blob, man = pack_state_dict(sd)
+        _CACHE[mode] = (to_torch_sd(sd), blob, man)
+    return _CACHE[mode]
+
+
+def _engine(mode, prec="f16", keep=True):
+    from emotivoice_amd.engine import EVEngine
+    key = ("eng", mode, prec, keep)
+    if key not in _CACHE:
+        eng = EVEngine(decoder_precision=prec, keep_stages=keep)
+        _, blob, man = _weights(mode)
+        eng.load_blob(blob, man)
+        _CACHE[key] = eng
+    return _CACHE[key]
+
+
+def _oracle(mode, utt, taps=None, durations=None):
+    from oracle import EVShapes, jets_forward
+    sd, _, _ = _weights(mode)
+    return jets_forward(sd, utt["ling"], utt["speaker"], utt["style"], utt["content"], EVShapes(), taps=taps, durations=durations)
+
+
+def _near_boundary(log_d, eps=2e-4):
+    v = np.exp(np.asarray(log_d, np.float64)) - 1.0
+    frac = v - np.floor(v)
+    return np.abs(frac - 0.5) < eps
+
+
+GOLDEN = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_fixture(gpu, path, prec):
+    """HIP path vs outputs of the reference itself (tests/golden/make_golden.py)."""
+    g = np.load(path)
+    eng = _engine(str(g["dur_mode"]), prec)
+    utt = dict(ling=g["in_ling"], speaker=int(g["in_speaker"]), style=g["in_style"], content=g["in_content"])
+    out = eng.synthesize([utt])
+    name = os.path.basename(path)[:-4] + "/" + prec
+    assert not _near_boundary(g["log_dur"]).any(), "fixture has a duration on a rounding boundary"
+    assert np.array_equal(out["durations"], g["dur"]), name
+    assert int(out["mel_lens"][0]) == int(g["mel_len"])
+    e = dict(log_dur=rel_l2(out["log_durations"], g["log_dur"]), pitch=rel_l2(out["pitch"], g["pitch"]),
+             energy=rel_l2(out["energy"], g["energy"]), mel=rel_l2(out["mel"], g["mel"]), wav=rel_l2(out["wav"], g["wav"]),
+             wav_ac=rel_l2_ac(out["wav"], g["wav"]))
+    _report("golden/" + name, e)
+    assert e["log_dur"] < TOL_F32_TAP and e["pitch"] < TOL_F32_TAP and e["energy"] < TOL_F32_TAP, e
+    assert e["mel"] < TOL_OUT, e
+    assert e["wav"] < TOL_OUT, e
+    assert out["wav"].shape[0] == 256 * int(g["mel_len"])
+    assert np.isfinite(out["wav"]).all() and np.abs(out["wav"]).max() <= 1.0
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_stage_taps_vs_oracle(gpu, prec):
+    """Every Appendix-C stage tap of one 48-phoneme utterance against the oracle."""
+    from oracle import synth_inputs
+    eng = _engine("parity", prec)
+    utt = synth_inputs(21, [48], [7])[0]
+    taps = {}
+    ref = _oracle("parity", utt, taps)
+    out = eng.synthesize([utt])
+    assert np.array_equal(out["durations"], ref["log_duration_predictions"].numpy())
+    errs = {}
+    f32_taps = ["tok_emb", "enc_l0", "enc_l1", "enc_l2", "enc_l3", "enc_out", "x_proj", "x_var", "upsampled"]
+    for name in f32_taps:
+        got = eng.get_stage(name).reshape(taps[name].shape)
+        errs[name] = rel_l2(got, taps[name].numpy())
+    for name in ["dec_l0", "dec_l1", "dec_l2", "dec_l3", "dec_out", "mel"]:
+        got = eng.get_stage(name).reshape(taps[name].shape)
+        errs[name] = rel_l2(got, taps[name].numpy())
+    for name in ["voc_pre", "voc_up0", "voc_mrf0", "voc_up1", "voc_mrf1", "voc_up2", "voc_mrf2", "voc_up3", "voc_mrf3"]:
+        r = taps[name].numpy().T     # oracle keeps (C, L); engine is channels-last (L, C)
+        got = eng.get_stage(name).reshape(r.shape)
+        errs[name] = rel_l2(got, r)
+    errs["wav"] = rel_l2(out["wav"], taps["wav"].numpy())
+    errs["wav_ac"] = rel_l2_ac(out["wav"], taps["wav"].numpy())
+    _report("taps/" + prec, errs)
+    for name in f32_taps:
+        assert errs[name] < TOL_F32_TAP, (name, errs)
+    dec_tol = TOL_F32_TAP if prec == "f32" else TOL_OUT
+    for name in ["dec_l0", "dec_l1", "dec_l2", "dec_l3", "dec_out", "mel"]:
+        assert errs[name] < dec_tol, (name, errs)
+    for name, v in errs.items():
+        assert v < TOL_OUT, (name, errs)
+
+
+def test_ragged_batch_equals_per_utterance_reference(gpu):
+    """Reference semantics are B = 1 per utterance: a ragged batch must reproduce the
+    per-utterance oracle, including utterances that straddle GEMM tile boundaries and a 1-phoneme utterance."""
+    from oracle import synth_inputs
+    eng = _engine("parity", "f16")
+    lens = [64, 9, 130, 1, 257, 40]
+    utts = synth_inputs(31, lens, [0, 3, 2013, 77, 5, 1000])
+    out = eng.synthesize(utts)
+    cu = out["cu_seqlens"]
+    errs = {}
+    for b, u in enumerate(utts):
+        ref = _oracle("parity", u)
+        d = out["durations"][cu[b]:cu[b + 1]]
+        near = _near_boundary(ref["log_dur_raw"].numpy())
+        assert np.array_equal(d[~near], ref["log_duration_predictions"].numpy()[~near]), b
+        if near.any() and not np.array_equal(d, ref["log_duration_predictions"].numpy()):
+            errs[f"utt{b}"] = "duration on rounding boundary differs; downstream compared with forced durations"
+            continue
+        assert int(out["mel_lens"][b]) == int(ref["mel_len"])
+        errs[f"utt{b}"] = dict(mel=rel_l2(out["mel_list"][b], ref["dec_outputs"].numpy()),
+                               wav=rel_l2(out["wav_list"][b], ref["wav_predictions"].numpy()))
+        assert errs[f"utt{b}"]["mel"] < TOL_OUT and errs[f"utt{b}"]["wav"] < TOL_OUT, errs
+    _report("ragged", errs)
+
+
+def test_batch_invariance_bit_exact(gpu):
+    """An utterance synthesised alone and inside a batch gives bit-identical outputs (per-utterance B=1
+    semantics; no cross-utterance leakage through conv halos, attention or the length regulator)."""
+    from oracle import synth_inputs
+    eng = _engine("parity", "f16")
+    utts = synth_inputs(41, [50, 120, 33], [1, 2, 3])
+    batch = eng.synthesize(utts)
+    wavs = [w.copy() for w in batch["wav_list"]]
+    mels = [m.copy() for m in batch["mel_list"]]
+    cu = batch["cu_seqlens"]
+    durs = [batch["durations"][cu[b]:cu[b + 1]].copy() for b in range(3)]
+    for b, u in enumerate(utts):
+        solo = eng.synthesize([u])
+        assert np.array_equal(solo["durations"], durs[b])
+        assert np.array_equal(solo["mel"], mels[b]), b
+        assert np.array_equal(solo["wav"], wavs[b]), b
+
+
+def test_forced_durations_and_zero_duration_guard(gpu):
+    """Teacher-forced durations incl. zeros, and the all-zero guard of alignment.py:187-191."""
+    from oracle import synth_inputs
+    eng = _engine("parity", "f16")
+    utt = synth_inputs(51, [20], [9])[0]
+    dur = np.array([0, 3, 0, 0, 7, 1, 2, 0, 5, 4, 0, 0, 0, 6, 2, 2, 1, 0, 9, 3], np.int64)
+    ref = _oracle("parity", utt, durations=torch.from_numpy(dur))
+    out = eng.synthesize([utt], forced_durations=dur)
+    assert int(out["mel_lens"][0]) == int(dur.sum()) == int(ref["mel_len"])
+    assert rel_l2(out["mel"], ref["dec_outputs"].numpy()) < TOL_OUT
+    assert rel_l2(out["wav"], ref["wav_predictions"].numpy()) < TOL_OUT
+    zero = np.zeros(20, np.int64)
+    ref0 = _oracle("parity", utt, durations=torch.from_numpy(zero))
+    out0 = eng.synthesize([utt], forced_durations=zero)
+    assert int(out0["mel_lens"][0]) == 20 == int(ref0["mel_len"])     # every duration becomes 1
+    assert rel_l2(out0["mel"], ref0["dec_outputs"].numpy()) < TOL_OUT
+
+
+def test_vocoder_only_and_int16(gpu):
+    """ev_vocoder on oracle mels (fp32 and fp16 inputs, ragged) + the caller's int16 epilogue."""
+    from oracle import EVShapes, hifigan_forward, synth_inputs
+    from oracle.jets_oracle import wav_to_int16
+    eng = _engine("parity", "f16")
+    sd, _, _ = _weights("parity")
+    rng = np.random.default_rng(5)
+    mels = [(1.25 * rng.standard_normal((80, T)) + 0.08).astype(np.float32) for T in (37, 5, 150)]
+    refs = [hifigan_forward(sd, torch.from_numpy(m), EVShapes()).numpy() for m in mels]
+    out = eng.vocoder(mels, want_int16=True)
+    errs = [rel_l2(w, r) for w, r in zip(out["wav_list"], refs)]
+    _report("vocoder_only_f32in", errs)
+    assert max(errs) < TOL_OUT, errs
+    assert np.array_equal(out["wav_i16"], wav_to_int16(out["wav"]))
+    out16 = eng.vocoder([m.astype(np.float16) for m in mels])
+    refs16 = [hifigan_forward(sd, torch.from_numpy(m.astype(np.float16).astype(np.float32)), EVShapes()).numpy() for m in mels]
+    assert max(rel_l2(w, r) for w, r in zip(out16["wav_list"], refs16)) < TOL_OUT
+
+
+def test_config2_shape_properties(gpu):
+    """BASELINE config 2 at full size (B=32 x 256 phonemes, bench weights): size-independent properties --
+    exact durations (4 frames / phoneme), exact lengths, bounded finite audio, and the first / last
+    utterance identical to their stand-alone synthesis."""
+    from oracle import synth_inputs
+    eng = _engine("bench", "f16", keep=False)
+    utts = synth_inputs(1, [256] * 32, [0] * 32)
+    out = eng.synthesize(utts)
+    assert (out["durations"] == 4).all()
+    assert (out["mel_lens"] == 1024).all()
+    assert out["wav"].shape[0] == 32 * 1024 * 256
+    assert np.isfinite(out["wav"]).all() and np.abs(out["wav"]).max() <= 1.0
+    first, last = out["wav_list"][0].copy(), out["wav_list"][31].copy()
+    assert np.array_equal(eng.synthesize([utts[0]])["wav"], first)
+    assert np.array_equal(eng.synthesize([utts[31]])["wav"], last)
+    # and one of them against the oracle
+    ref = _oracle("bench", utts[31])
+    e = rel_l2(last, ref["wav_predictions"].numpy())
+    _report("config2_utt31_wav", e)
+    assert e < TOL_OUT

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box via:  gpurun --timeout 2400 -- 'bash tools/gpu_check.sh [stage...]'
+# Stages: ops parity smoke bench prof    (default: ops parity smoke bench)
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+STAGES="${@:-ops parity smoke bench}"
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > gpurun_out/device.log
+nproc >> gpurun_out/device.log
+for st in $STAGES; do
+  case $st in
+    ops)    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 600 > gpurun_out/ops.log 2>&1; echo "ops rc=$?";;
+    parity) timeout 1800 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 900 > gpurun_out/parity.log 2>&1; echo "parity rc=$?";;
+    smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?";;
+    bench)  timeout 900 python bench.py --steps 5 --warmup 2 --cpu-utts 4 > gpurun_out/bench.log 2>&1; echo "bench rc=$?";;
+    prof)   cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --cpu-utts 0 > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$GRAFT_REPO_ROOT";;
+  esac
+done
+tail -n 30 gpurun_out/ops.log gpurun_out/parity.log gpurun_out/smoke.log gpurun_out/bench.log 2>/dev/null | tail -n 120
