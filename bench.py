@@ -36,16 +36,23 @@ def cpu_baseline(n_utts, phonemes):
     from oracle import EVShapes, jets_forward
     from oracle.jets_oracle import to_torch_sd
     from emotivoice_amd.synthetic import synth_inputs, synth_state_dict
-    cores = os.cpu_count() or 1
+    # 256 torch threads on the GPU box's 2x64-core EPYC run ~100x slower than 16 (oversubscription); the reference
+    # itself pins a handful of threads per worker (inference_tts.py:186 uses 4).  16 is what we time and report.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("EV_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     sd = to_torch_sd(synth_state_dict(0, "bench"))
     utts = synth_inputs(1, [phonemes] * (n_utts + 1), None)
     jets_forward(sd, utts[0]["ling"], 0, utts[0]["style"], utts[0]["content"], EVShapes())   # warm-up
     frames = 0
     t0 = time.perf_counter()
+    done = 0
     for u in utts[1:]:
         o = jets_forward(sd, u["ling"], 0, u["style"], u["content"], EVShapes())
         frames += int(o["mel_len"])
+        done += 1
+        if time.perf_counter() - t0 > 25.0:      # bounded sample: ~10-30 s of CPU work
+            break
+    n_utts = done
     dt = time.perf_counter() - t0
     return dict(value=frames / dt, unit="mel-frames/s", cores=cores, kind="port",
                 sample="%d utterances x %d phonemes, B=1 loop, fp32 torch-CPU oracle, %.1f s" % (n_utts, phonemes, dt))
