@@ -20,6 +20,7 @@
 // models/prompt_tts_modified/modules/encoder.py:50-52,72-109, modules/variance.py:41-46,
 // model_open_source.py:111,147 and models/hifigan/models.py:50-57,116-128.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "ev_kernels.h"
 
@@ -28,7 +29,6 @@ namespace ev {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int ROWB = 80;   // LDS pitch of one staged row: 64 B payload + 16 B pad
 static constexpr int MAX_SPAN = 64;
 
 __device__ __forceinline__ uint4 lrelu_h8(uint4 v, float slope) {
@@ -54,25 +54,140 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
+// ---- coalesced epilogue: every wave transposes its accumulator tile through LDS (32 rows at a time) so that each lane
+// ends up with 8 CONSECUTIVE output channels of one time step and a wave-instruction stores whole 64..128-byte row segments
+// of consecutive rows (the MFMA layout gives 4 channels x 16 strided rows per lane: 32-byte segments, which measured at
+// 20 % (C=128) to 60 % (C=32) of the kernel time).  Bias / activation / residual / MRF accumulate are applied on the
+// coalesced side with 16/32-byte loads.
+template <int TC>
+__device__ __forceinline__ constexpr int epi_pitch() { return TC * 4 + 16; }
+template <int TC>
+__device__ __forceinline__ constexpr int epi_wave_bytes() { return 32 * epi_pitch<TC>(); }
+
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0) {
+    constexpr int TC = NT * 16;
+    constexpr int PITCH = epi_pitch<TC>();
+    constexpr int LPR = TC / 8;          // lanes per row (8 channels each)
+    constexpr int RPI = 64 / LPR;        // rows per wave-instruction
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane / LPR, g = lane % LPR;
+    const int co = co0 + g * 8;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+#pragma unroll
+    for (int pass = 0; pass < MT / 2; ++pass) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                *reinterpret_cast<f32x4*>(wave_lds + (bb * 16 + fr) * PITCH + (a * 16 + 4 * fq) * 4) = acc[a][pass * 2 + bb];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int lr = it * RPI + rr;
+            const int t = t0 + pass * 32 + lr;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const bool valid = p.row_valid ? (p.row_valid[t >> p.valid_shift] != 0) : true;
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+                if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act, p.act_slope);
+                }
+                if (p.seq_bias) {
+                    const float* sb = p.seq_bias + (long)p.row_seq[t] * p.ld_seq_bias + co;
+                    const float4 s0 = *reinterpret_cast<const float4*>(sb), s1 = *reinterpret_cast<const float4*>(sb + 4);
+                    v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+                }
+                if (p.res) {
+                    if (p.res_dtype == DT_F16) {
+                        const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.res) + (long)t * p.ldres + co);
+                        const __half2* h = reinterpret_cast<const __half2*>(&r);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); v[2 * e] += f.x; v[2 * e + 1] += f.y; }
+                    } else {
+                        const float* rp = reinterpret_cast<const float*>(p.res) + (long)t * p.ldres + co;
+                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+                if (p.acc32) {
+                    const float* rp = p.acc32 + (long)t * p.ldacc + co;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            if (p.out32 && p.out32_before_post) {
+                float* op = p.out32 + (long)t * p.ldo + co;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (p.post_lrelu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.post_slope;
+            }
+            if (p.out32 && !p.out32_before_post) {
+                float* op = p.out32 + (long)t * p.ldo + co;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (p.out16) {
+                uint4 o;
+                __half2* h = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.out16) + (long)t * p.ldo + co) = o;
+            }
+        }
+    }
+}
+
+// ---- main kernel.  LDS: 64-byte pitch with an XOR swizzle (16-B part ^= (row >> 1) & 3): conflict-free ds_read_b128 for
+// the 16-row fragment reads at ANY tap offset and conflict-free ds_write_b128 staging (bank model of MI355X_MICROARCH.md
+// section LDS; the first version's 80-B padded pitch measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50).
+// Pipeline: the weight tile of step s+2 is loaded into registers while step s computes and is written to LDS one step
+// later; the activation slab of K-chunk kc+1 is loaded at the first tap of chunk kc and written at its last tap.
+// The steady-state loop body is branch-free (clamped addresses instead of predicates, exact chunk counts) so that hipcc
+// keeps counted vmcnt waits; register sets rotate by moves (a runtime A/B parity or lambdas taking array references made
+// hipcc spill the prefetch registers to scratch inside the loop).
+__device__ __forceinline__ int swz(int row, int part) { return row * 64 + ((part ^ ((row >> 1) & 3)) << 4); }
+
 template <typename TIn, int BM, int BN, int WT, int WC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
     constexpr int ES = sizeof(TIn);
     constexpr int TT = BM / WT, TC = BN / WC, MT = TT / 16, NT = TC / 16;
-    constexpr int XCH = ((BM + MAX_SPAN) * 4 + 255) / 256;   // 16-B chunks per thread for the X slab
+    constexpr int SLAB = BM + MAX_SPAN;              // rows staged per K-chunk (>= BM + (taps-1)*dil, multiple of 64)
+    constexpr int XCH = SLAB * 4 / 256;              // 16-B chunks per thread
     constexpr int WCH = (BN * 4 + 255) / 256;
-    static_assert(WT * WC == 4, "4 waves per block");
+    static_assert(WCH <= 2, "weight tile staging uses at most two 16-B chunks per thread");
+    constexpr int XBUF = SLAB * 64, WBUF = BN * 64;
+    static_assert(WT * WC == 4 && SLAB % 64 == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wt = wave / WC, wc = wave % WC;
-
-    const int span = (p.taps - 1) * p.dil;
-    const int slab_rows = BM + span;
-    const int xbuf_bytes = slab_rows * ROWB;
     char* Xs = smem;
-    char* Ws = smem + 2 * xbuf_bytes;
+    char* Ws = smem + 2 * XBUF;
 
     // XCD-aware block remap (bijective): consecutive logical tiles -> same XCD (shared L2 for the A rows)
     const int nN = p.N / BN;
@@ -85,61 +200,50 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     const int mb = bid / nN, nb = bid % nN;
     const int m0 = mb * BM, n0 = nb * BN;
 
+    const int taps = p.taps;
     const int nkc = (p.K * ES) >> 6;
-    const int steps = nkc * p.taps;
-    const char* Ag = reinterpret_cast<const char*>(p.A);
-    const char* Wg = reinterpret_cast<const char*>(p.W);
     const long a_pitch = (long)p.lda * ES;
     const long w_tap_pitch = (long)p.K * ES;
-    const long w_row_pitch = w_tap_pitch * p.taps;
-    const int x_chunks = slab_rows * 4;
-    const long a_row0 = (long)m0 - (long)p.center * p.dil;
+    const long w_row_pitch = w_tap_pitch * taps;
 
-    uint4 xr[XCH], wr[WCH];
+    // per-thread staging sources / swizzled LDS destinations (no predicates: SLAB*4 and the W chunk count are multiples
+    // of the block size, or wrap around onto duplicate chunks for BN = 32)
+    const char* xsrc[XCH]; int xdst[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + i * 256, r = c >> 2, part = c & 3;
+        xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + r) * a_pitch + part * 16;
+        xdst[i] = swz(r, part);
+    }
+    const char* wsrc[WCH]; int wdst[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int c = (tid + i * 256) % (BN * 4), r = c >> 2, part = c & 3;
+        wsrc[i] = reinterpret_cast<const char*>(p.W) + (long)(n0 + r) * w_row_pitch + part * 16;
+        wdst[i] = swz(r, part);
+    }
 
-    auto gload_x = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int c = tid + i * 256;
-            if (c < x_chunks) {
-                const int r = c >> 2, part = c & 3;
-                xr[i] = *reinterpret_cast<const uint4*>(Ag + (a_row0 + r) * a_pitch + (long)kc * 64 + part * 16);
-            }
-        }
-    };
-    auto sstore_x = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int c = tid + i * 256;
-            if (c < x_chunks) {
-                const int r = c >> 2, part = c & 3;
-                uint4 v = xr[i];
-                if (p.pro_lrelu) v = (ES == 2) ? lrelu_h8(v, p.pro_slope) : lrelu_f4(v, p.pro_slope);
-                *reinterpret_cast<uint4*>(Xs + buf * xbuf_bytes + r * ROWB + part * 16) = v;
-            }
-        }
-    };
-    auto gload_w = [&](int kc, int tap) {
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + i * 256;
-            if (c < BN * 4) {
-                const int r = c >> 2, part = c & 3;
-                wr[i] = *reinterpret_cast<const uint4*>(Wg + (long)(n0 + r) * w_row_pitch + (long)tap * w_tap_pitch +
-                                                        (long)kc * 64 + part * 16);
-            }
-        }
-    };
-    auto sstore_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + i * 256;
-            if (c < BN * 4) {
-                const int r = c >> 2, part = c & 3;
-                *reinterpret_cast<uint4*>(Ws + buf * (BN * ROWB) + r * ROWB + part * 16) = wr[i];
-            }
-        }
-    };
+    uint4 xr[XCH];
+    uint4 wA0, wA1, wB0, wB1;   // scalars, not arrays: hipcc kept uint4 wA[2]/wB[2] in scratch
+    wA1 = wB1 = make_uint4(0, 0, 0, 0);
+#define EV_GLOAD_X(KC) \
+    _Pragma("unroll") for (int i = 0; i < XCH; ++i) xr[i] = *reinterpret_cast<const uint4*>(xsrc[i] + (long)(KC) * 64);
+#define EV_SSTORE_X(BUF)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                            \
+        uint4 v_ = xr[i];                                                                        \
+        if (p.pro_lrelu) v_ = (ES == 2) ? lrelu_h8(v_, p.pro_slope) : lrelu_f4(v_, p.pro_slope); \
+        *reinterpret_cast<uint4*>(Xs + (BUF) * XBUF + xdst[i]) = v_;                             \
+    }
+#define EV_GLOAD_W(DST, KC, TAP)                                                                                     \
+    {                                                                                                                \
+        DST##0 = *reinterpret_cast<const uint4*>(wsrc[0] + (long)(TAP) * w_tap_pitch + (long)(KC) * 64);             \
+        if constexpr (WCH > 1) DST##1 = *reinterpret_cast<const uint4*>(wsrc[WCH - 1] + (long)(TAP) * w_tap_pitch + (long)(KC) * 64); \
+    }
+#define EV_SSTORE_W(SRC, BUF)                                                                  \
+    {                                                                                          \
+        *reinterpret_cast<uint4*>(Ws + (BUF) * WBUF + wdst[0]) = SRC##0;                       \
+        if constexpr (WCH > 1) *reinterpret_cast<uint4*>(Ws + (BUF) * WBUF + wdst[WCH - 1]) = SRC##1; \
+    }
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -147,131 +251,111 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload_x(0);
-    gload_w(0, 0);
-    sstore_x(0);
-    sstore_w(0);
+    const int fr = lane & 15, fq = lane >> 4;
+    int woff[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) woff[a] = swz(wc * TC + a * 16 + fr, fq);
+
+#define EV_COMPUTE(WBUFSEL, KC, TAP)                                                                           \
+    {                                                                                                          \
+        const int row0_ = wt * TT + fr + (TAP) * p.dil;                                                        \
+        const char* Xb_ = Xs + ((KC) & 1) * XBUF + row0_ * 64 + ((fq ^ ((row0_ >> 1) & 3)) << 4);               \
+        const char* Wb_ = Ws + (WBUFSEL) * WBUF;                                                               \
+        uint4 xf[MT], wf[NT];                                                                                  \
+        _Pragma("unroll") for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xb_ + b * 16 * 64); \
+        _Pragma("unroll") for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(Wb_ + woff[a]);  \
+        _Pragma("unroll") for (int a = 0; a < NT; ++a) {                                                       \
+            _Pragma("unroll") for (int b = 0; b < MT; ++b) {                                                   \
+                if constexpr (ES == 2) {                                                                       \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf[a]),      \
+                                                                       *reinterpret_cast<half8*>(&xf[b]), acc[a][b], 0, 0, 0); \
+                } else {                                                                                       \
+                    const float* wa_ = reinterpret_cast<const float*>(&wf[a]);                                 \
+                    const float* xb_ = reinterpret_cast<const float*>(&xf[b]);                                 \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_[e], xb_[e], acc[a][b], 0, 0, 0);  \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    // prologue: X(0), W(step 0) -> LDS; W(step 1) -> registers
+    EV_GLOAD_X(0)
+    EV_GLOAD_W(wA, 0, 0)
+    EV_SSTORE_X(0)
+    EV_SSTORE_W(wA, 0)
+    {
+        const int k1 = (taps > 1) ? 0 : (nkc > 1 ? 1 : 0), t1 = (taps > 1) ? 1 : 0;
+        EV_GLOAD_W(wB, k1, t1)
+    }
     __syncthreads();
 
-    const int frag_off = (lane & 15) * ROWB + (lane >> 4) * 16;
+    int wsel = 0;                        // LDS weight buffer holding the current step's tile
     int kc = 0, tap = 0;
-    for (int s = 0; s < steps; ++s) {
-        int ntap = tap + 1, nkc_ = kc;
-        if (ntap == p.taps) { ntap = 0; nkc_ = kc + 1; }
-        const bool has_next = (s + 1 < steps);
-        const bool next_x = has_next && (ntap == 0);
-        if (has_next) gload_w(nkc_, ntap);
-        if (next_x) gload_x(nkc_);
-
-        const char* Xb = Xs + (kc & 1) * xbuf_bytes + (wt * TT + tap * p.dil) * ROWB + frag_off;
-        const char* Wb = Ws + (s & 1) * (BN * ROWB) + (wc * TC) * ROWB + frag_off;
-        uint4 xf[MT], wf[NT];
-#pragma unroll
-        for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xb + b * 16 * ROWB);
-#pragma unroll
-        for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(Wb + a * 16 * ROWB);
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-#pragma unroll
-            for (int b = 0; b < MT; ++b) {
-                if constexpr (ES == 2) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf[a]),
-                                                                       *reinterpret_cast<half8*>(&xf[b]), acc[a][b], 0, 0, 0);
-                } else {
-                    const float* wa = reinterpret_cast<const float*>(&wf[a]);
-                    const float* xb = reinterpret_cast<const float*>(&xf[b]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xb[e], acc[a][b], 0, 0, 0);
-                }
-            }
-        }
-        if (has_next) sstore_w((s + 1) & 1);
-        if (next_x) sstore_x(nkc_ & 1);
-        __syncthreads();
-        tap = ntap;
-        kc = nkc_;
+    const int steps = nkc * taps;
+    // One pipeline step.  LD receives W(s+2) (clamped to a valid tile at the very end: loaded, never used); ST holds W(s+1),
+    // loaded one step ago, and is written to the idle LDS buffer.  Two textual copies with the register sets swapped give a
+    // static A/B parity (no register moves: a move is a "use" and drags the vmcnt wait to the top of the next step).
+#define EV_STEP(LD, ST)                                                                    \
+    {                                                                                      \
+        const bool more_ = kc + 1 < nkc;                                                   \
+        int t2_ = tap + 2, k2_ = kc;                                                       \
+        if (t2_ >= taps) { t2_ -= taps; k2_ = kc + 1; }                                    \
+        if (t2_ >= taps) { t2_ -= taps; k2_ += 1; }                                        \
+        if (k2_ >= nkc) { k2_ = kc; t2_ = tap; }                                           \
+        EV_GLOAD_W(LD, k2_, t2_)                                                           \
+        if (tap == 0 && more_) { EV_GLOAD_X(kc + 1) }                                      \
+        EV_COMPUTE(wsel, kc, tap)                                                          \
+        EV_SSTORE_W(ST, wsel ^ 1)                                                          \
+        if (tap == taps - 1) {                                                             \
+            if (more_) { EV_SSTORE_X((kc + 1) & 1) }                                       \
+            tap = 0; ++kc;                                                                 \
+        } else {                                                                           \
+            ++tap;                                                                         \
+        }                                                                                  \
+        __syncthreads();                                                                   \
+        wsel ^= 1;                                                                         \
     }
-
-    // ---- epilogue: lane holds D[co0..co0+3][t] for each (a, b) tile
-    const int t_base = m0 + wt * TT + (lane & 15);
-    const int co_base = n0 + wc * TC + 4 * (lane >> 4);
-#pragma unroll
-    for (int b = 0; b < MT; ++b) {
-        const int t = t_base + b * 16;
-        const bool valid = p.row_valid ? (p.row_valid[t >> p.valid_shift] != 0) : true;
-        const float* sb = nullptr;
-        if (p.seq_bias && valid) sb = p.seq_bias + (long)p.row_seq[t] * p.ld_seq_bias;
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const int co = co_base + a * 16;
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            if (valid) {
-                if (p.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + co);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (p.act != ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.act_slope);
-                }
-                if (sb) {
-                    const float4 bb = *reinterpret_cast<const float4*>(sb + co);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (p.res) {
-                    if (p.res_dtype == DT_F16) {
-                        const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(p.res) + (long)t * p.ldres + co);
-                        const __half2* h = reinterpret_cast<const __half2*>(&rr);
-                        const float2 f0 = __half22float2(h[0]), f1 = __half22float2(h[1]);
-                        v[0] += f0.x; v[1] += f0.y; v[2] += f1.x; v[3] += f1.y;
-                    } else {
-                        const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (long)t * p.ldres + co);
-                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-                if (p.acc32) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.acc32 + (long)t * p.ldacc + co);
-                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                }
-                if (p.out32 && p.out32_before_post)
-                    *reinterpret_cast<float4*>(p.out32 + (long)t * p.ldo + co) = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.post_lrelu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.post_slope;
-                }
-            } else {
-                v[0] = v[1] = v[2] = v[3] = 0.f;
-                if (p.out32 && p.out32_before_post)
-                    *reinterpret_cast<float4*>(p.out32 + (long)t * p.ldo + co) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (p.out32 && !p.out32_before_post)
-                *reinterpret_cast<float4*>(p.out32 + (long)t * p.ldo + co) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.out16) {
-                uint2 o;
-                __half2* h = reinterpret_cast<__half2*>(&o);
-                h[0] = __floats2half2_rn(v[0], v[1]);
-                h[1] = __floats2half2_rn(v[2], v[3]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(p.out16) + (long)t * p.ldo + co) = o;
-            }
-        }
+    int s = 0;
+    for (; s + 1 < steps; s += 2) {
+        EV_STEP(wA, wB)
+        EV_STEP(wB, wA)
     }
+    if (s < steps) EV_STEP(wA, wB)
+#undef EV_STEP
+#undef EV_COMPUTE
+#undef EV_GLOAD_X
+#undef EV_SSTORE_X
+#undef EV_GLOAD_W
+#undef EV_SSTORE_W
+
+    // all waves passed the barrier that ended the last step: the staging buffers are free for the transpose
+    gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
 }
 
 template <typename TIn, int BM, int BN, int WT, int WC>
 static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     const int span = (p.taps - 1) * p.dil;
-    const size_t lds = 2 * (size_t)(BM + span) * ROWB + 2 * (size_t)BN * ROWB;
     const int grid = (p.M / BM) * (p.N / BN);
+    (void)span;
+    size_t lds = 2 * (size_t)(BM + MAX_SPAN) * 64 + 2 * (size_t)BN * 64;
+    const size_t epi = 4 * (size_t)(32 * ((BN / WC) * 4 + 16));
+    if (epi > lds) lds = epi;
     hipLaunchKernelGGL((conv_gemm_kernel<TIn, BM, BN, WT, WC>), dim3(grid), dim3(256), lds, s, p);
 }
 
 template <typename TIn>
 static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
-    if (p.N % 128 == 0) launch_cfg<TIn, 128, 128, 2, 2>(p, s);
-    else if (p.N % 64 == 0) launch_cfg<TIn, 256, 64, 4, 1>(p, s);
+    if (p.N % 128 == 0) {
+        // 256-row tiles halve the weight-tile traffic per FLOP (the measured bottleneck of deep reductions); short reductions
+        // (few (K-chunk, tap) steps per tile) prefer 128 rows: prologue/epilogue dominate and more tiles are in flight
+        static const char* force = getenv("EV_GEMM_TILE");            // "128" / "256": A/B switch for tools/bench_gemm.py
+        const int steps = (p.K * (int)sizeof(TIn) / 64) * p.taps;
+        bool big = steps >= 28 || p.N >= 512;
+        if (force) big = force[0] == '2';
+        if (big) launch_cfg<TIn, 256, 128, 2, 2>(p, s);
+        else launch_cfg<TIn, 128, 128, 2, 2>(p, s);
+    } else if (p.N % 64 == 0) launch_cfg<TIn, 256, 64, 4, 1>(p, s);
     else launch_cfg<TIn, 256, 32, 4, 1>(p, s);
 }
 
