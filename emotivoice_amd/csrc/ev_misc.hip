@@ -2,6 +2,7 @@
 // All activations are channels-last [rows][channels]; "rows" follow the gap layout described in
 // DESIGN.md (utterances separated by >= 4 zero rows; invalid rows are always written as zeros).
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "ev_kernels.h"
 
@@ -218,10 +219,195 @@ __global__ __launch_bounds__(64) void attention_kernel(const AttnParams p) {
         for (int d = 0; d < DK; ++d) op[d] = (T)(o[d] * inv);
     }
 }
+// ---- fp16 MFMA flash attention (decoder): 128 queries per block (4 waves x 2 tiles of 16), keys/values streamed in
+// tiles of 64 through double-buffered LDS, online softmax in registers.
+// Both products are computed TRANSPOSED so that probabilities never leave registers:
+//   S^T[key][query] = K . Q^T   (A = K tile rows, B = Q fragment held in registers for the whole kernel;
+//                                d_k = 48 = one 16x16x32 MFMA + one 16x16x16 MFMA)
+//   O^T[d][query]  += V^T . P^T (A = V^T from LDS, B = P packed straight from the S^T accumulators)
+// The MFMA C layout gives lane (query j, group g) the keys {16*kt + 4g + r}; the k-slot order of the P.V MFMA is
+// permuted to exactly that set (slots 0-3: keys 32*kb + 4g + r, slots 4-7: keys 32*kb + 16 + 4g + r), which only
+// requires V^T to be read with the same permutation (two 8-byte LDS reads) -- any k permutation applied to both
+// operands leaves the product unchanged.  The softmax max/sum of a query lives in the 4 lanes (j, g=0..3): two
+// shuffles per tile.  reference: modules/encoder.py:72-109 (mask = None / all-valid for B = 1).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p) {
+    constexpr int DK = 48, KP = 112, VP = 144;         // LDS pitches (bytes): K rows 96 B + 16, V^T rows 128 B + 16
+    constexpr int KBYTES = 64 * KP, VBYTES = DK * VP;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (KBYTES + VBYTES)];
+    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
+    const int len = p.seq_len[b];
+    if (qblk * 128 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const long row0 = p.seq_off[b];
+    const _Float16* base = reinterpret_cast<const _Float16*>(p.qkv);
+
+    h8 q32[2];
+    h4 q16[2];
+    int qrow[2];
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+        qrow[nq] = qblk * 128 + wave * 32 + nq * 16 + fr;
+        const int qc = min(qrow[nq], len - 1);
+        const _Float16* qp = base + (row0 + qc) * p.ld + h * DK;
+        q32[nq] = *reinterpret_cast<const h8*>(qp + 8 * fg);
+        q16[nq] = *reinterpret_cast<const h4*>(qp + 32 + 4 * fg);
+    }
+    const float scale2 = 1.4426950408889634f / sqrtf((float)DK);    // log2(e) / sqrt(d_k): softmax in base 2
+
+    // staging: 64 keys x 96 B = 384 16-byte chunks for K and for V; 256 threads -> chunk tid and (tid < 128) chunk tid + 256
+    const int ntiles = (len + 63) >> 6;
+    // (scalar staging registers + macros: uint4 arrays captured by lambdas end up in scratch with hipcc)
+    uint4 kr0, kr1 = make_uint4(0, 0, 0, 0), vr0, vr1 = make_uint4(0, 0, 0, 0);
+    const int c1 = tid + 256;                       // second chunk, valid for tid < 128
+    const int key_a = tid / 6, part_a = tid % 6, key_b = c1 / 6, part_b = c1 % 6;
+    const long col_a = p.C + h * DK + part_a * 8, col_b = p.C + h * DK + part_b * 8;
+#define EV_AT_GLOAD(T)                                                                                   \
+    {                                                                                                    \
+        const _Float16* kp_ = base + (row0 + min((T) * 64 + key_a, len - 1)) * p.ld + col_a;             \
+        kr0 = *reinterpret_cast<const uint4*>(kp_);                                                      \
+        vr0 = *reinterpret_cast<const uint4*>(kp_ + p.C);                                                \
+        if (tid < 128) {                                                                                 \
+            const _Float16* kq_ = base + (row0 + min((T) * 64 + key_b, len - 1)) * p.ld + col_b;         \
+            kr1 = *reinterpret_cast<const uint4*>(kq_);                                                  \
+            vr1 = *reinterpret_cast<const uint4*>(kq_ + p.C);                                            \
+        }                                                                                                \
+    }
+#define EV_AT_SSTORE1(KR, VR, KEY, PART, KB_, VB_)                                                       \
+    {                                                                                                    \
+        *reinterpret_cast<uint4*>((KB_) + (KEY) * KP + (PART) * 16) = KR;                                \
+        const h8 hv_ = *reinterpret_cast<const h8*>(&VR);                                                \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                    \
+            *reinterpret_cast<_Float16*>((VB_) + ((PART) * 8 + e) * VP + (KEY) * 2) = hv_[e];            \
+    }
+#define EV_AT_SSTORE(BUF)                                                                                \
+    {                                                                                                    \
+        char* Kb_ = lds + (BUF) * (KBYTES + VBYTES);                                                     \
+        char* Vb_ = Kb_ + KBYTES;                                                                        \
+        EV_AT_SSTORE1(kr0, vr0, key_a, part_a, Kb_, Vb_)                                                 \
+        if (tid < 128) EV_AT_SSTORE1(kr1, vr1, key_b, part_b, Kb_, Vb_)                                  \
+    }
+
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    f4 o[2][3];
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) o[nq][dt] = f4{0.f, 0.f, 0.f, 0.f};
+
+    EV_AT_GLOAD(0)
+    EV_AT_SSTORE(0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) EV_AT_GLOAD(t + 1)
+        const char* Kb = lds + (t & 1) * (KBYTES + VBYTES);
+        const char* Vb = Kb + KBYTES;
+        f4 s[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const h8 ka32 = *reinterpret_cast<const h8*>(Kb + (kt * 16 + fr) * KP + 16 * fg);
+            const h4 ka16 = *reinterpret_cast<const h4*>(Kb + (kt * 16 + fr) * KP + 64 + 8 * fg);
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) {
+                f4 z = f4{0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka32, q32[nq], z, 0, 0, 0);
+                s[nq][kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ka16, q16[nq], z, 0, 0, 0);
+            }
+        }
+        h8 pb[2][2];
+        const int key0 = t * 64 + 4 * fg;
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[nq][kt][r] * scale2;
+                    if (key0 + kt * 16 + r >= len) v = -INFINITY;
+                    s[nq][kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m[nq], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[nq] - mn);
+            m[nq] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[nq][kt][r] - mn);
+                    s[nq][kt][r] = pv;
+                    ps += pv;
+                }
+            l[nq] = l[nq] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) o[nq][dt] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                h8 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pk[r] = (_Float16)s[nq][2 * kb][r];
+                    pk[4 + r] = (_Float16)s[nq][2 * kb + 1][r];
+                }
+                pb[nq][kb] = pk;
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const char* vp = Vb + (dt * 16 + fr) * VP + (kb * 32 + 4 * fg) * 2;
+                const h4 lo = *reinterpret_cast<const h4*>(vp);
+                const h4 hi = *reinterpret_cast<const h4*>(vp + 32);
+                const h8 va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int nq = 0; nq < 2; ++nq) o[nq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[nq][kb], o[nq][dt], 0, 0, 0);
+            }
+        if (more) EV_AT_SSTORE((t + 1) & 1)
+        __syncthreads();
+    }
+#undef EV_AT_GLOAD
+#undef EV_AT_SSTORE
+#undef EV_AT_SSTORE1
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+        float lt = l[nq];
+        lt += __shfl_xor(lt, 16);
+        lt += __shfl_xor(lt, 32);
+        const float inv = 1.0f / lt;
+        if (qrow[nq] < len) {
+            _Float16* op = reinterpret_cast<_Float16*>(p.out) + (row0 + qrow[nq]) * p.ldo + h * DK + 4 * fg;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                h4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (_Float16)(o[nq][dt][r] * inv);
+                *reinterpret_cast<h4*>(op + dt * 16) = ov;
+            }
+        }
+    }
+}
+
 void launch_attention(const AttnParams& p, hipStream_t s) {
-    dim3 grid((p.max_len + 63) / 64, p.heads, p.B);
-    if (p.dtype == DT_F16) hipLaunchKernelGGL((attention_kernel<_Float16, 48>), grid, dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((attention_kernel<float, 48>), grid, dim3(64), 0, s, p);
+    if (p.dtype == DT_F16) {
+        static const bool valu = getenv("EV_ATTN_VALU") != nullptr;     // A/B switch: fp32-math VALU kernel on fp16 inputs
+        if (!valu) {
+            hipLaunchKernelGGL(attention_mfma_kernel, dim3((p.max_len + 127) / 128, p.heads, p.B), dim3(256), 0, s, p);
+            return;
+        }
+        hipLaunchKernelGGL((attention_kernel<_Float16, 48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(64), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((attention_kernel<float, 48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(64), 0, s, p);
+    }
 }
 
 // ------------------------------------------------------------------ conditioning vector

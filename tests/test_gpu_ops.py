@@ -224,7 +224,7 @@ def test_attention_ragged(lib, is_f16):
     """Attention restricted to each utterance's rows == per-utterance B=1 attention (modules/encoder.py:72-109)."""
     torch.manual_seed(7)
     Cc, H = 384, 8
-    lens = [70, 1, 130, 64]
+    lens = [70, 1, 130, 64, 300, 129, 1024]
     offs, rows = [], 4
     for n in lens:
         offs.append(rows)
@@ -242,4 +242,4 @@ def test_attention_ragged(lib, is_f16):
         q, k, v = [t.view(n, H, 48).transpose(0, 1) for t in blk.split(Cc, dim=1)]
         att = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(48), dim=-1) @ v
         ref = att.transpose(0, 1).reshape(n, Cc)
-        assert _rel(out[o:o + n].float().cpu(), ref) < (6e-4 if is_f16 else 2e-6)
+        assert _rel(out[o:o + n].float().cpu(), ref) < (1e-3 if is_f16 else 2e-6), (n, is_f16)
