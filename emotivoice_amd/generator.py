@@ -1,0 +1,195 @@
+"""Drop-in mirror of the reference's ``JETSGenerator`` object protocol on top of libevhip.so.
+
+The reference boundary for the hot path is a Python object:
+``JETSGenerator(conf).to(device)``, ``.load_state_dict(ckpt['generator'])``, ``.eval()`` and
+``generator(inputs_ling=..., inputs_style_embedding=..., input_lengths=..., inputs_content_embedding=...,
+inputs_speaker=..., alpha=1.0)`` returning a dict whose ``wav_predictions`` the callers scale to int16
+(models/prompt_tts_modified/jets.py:26-71, inference_am_vocoder_joint.py:70-74,122-131).
+``JETSGeneratorHIP`` keeps names, argument meaning, return keys and error behaviour; everything between is
+the C ABI of include/evhip.h.  Only the inference branch exists: ``mel_targets`` must be None.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from .config import EVShapes, from_reference_config
+from .engine import EVEngine, EVError
+from .packer import pack_state_dict
+
+_IGNORED_PREFIXES = ("am.alignment_module.",)      # present in checkpoints, unused at inference
+
+
+class _DevArray:
+    """Expose a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class JETSGeneratorHIP:
+    def __init__(self, config=None, decoder_precision: str = "f16", keep_stages: bool = False, pe_len: int = 4096):
+        self.config = config
+        self.shapes: EVShapes = from_reference_config(config)
+        self.segment_size = self.shapes.segment_size
+        self.upsample_factor = self.shapes.upsample_factor
+        self._prec, self._keep, self._pe_len = decoder_precision, keep_stages, pe_len
+        self._device_id: Optional[int] = None
+        self._engine: Optional[EVEngine] = None
+        self._blob = None
+        self.training = False
+
+    # ---- nn.Module-like surface used by the reference callers
+    def to(self, device):
+        dev_id = device if isinstance(device, int) else None
+        if dev_id is None:
+            s = str(device)
+            if s == "cpu":
+                raise EVError("JETSGeneratorHIP has no CPU path: it needs a HIP device (cuda:N)")
+            dev_id = int(s.split(":")[1]) if ":" in s else 0
+        if self._engine is not None and dev_id != self._device_id:
+            self._engine.close()
+            self._engine = None
+        self._device_id = dev_id
+        self._ensure_engine()
+        return self
+
+    def cuda(self, device=0):
+        return self.to(device if isinstance(device, int) else str(device))
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("training is out of scope: JETSGeneratorHIP implements the inference branch of jets.py:61-66")
+        return self
+
+    def _ensure_engine(self):
+        if self._engine is None:
+            self._engine = EVEngine(self.shapes, self._device_id or 0, self._prec, self._keep)
+            if self._blob is not None:
+                self._engine.load_blob(*self._blob)
+        return self._engine
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts ``ckpt['generator']`` (422 tensors, ``am.*`` / ``generator.*``; torch>=2.1 parametrization keys or the
+        legacy weight_g / weight_v keys).  strict=True mirrors torch: a missing tensor raises KeyError."""
+        if strict:
+            known = ("am.", "generator.", "module.am.", "module.generator.")
+            bad = [k for k in state_dict if not k.startswith(known)]
+            if bad:
+                raise RuntimeError("Unexpected key(s) in state_dict: " + ", ".join(bad[:5]))
+        self._blob = pack_state_dict(state_dict, self.shapes, self._pe_len)
+        if self._engine is not None:
+            self._engine.load_blob(*self._blob)
+        return self
+
+    def load_packed(self, blob: bytes, manifest_json: Optional[str] = None):
+        self._blob = (blob, manifest_json)
+        if self._engine is not None:
+            self._engine.load_blob(blob, manifest_json)
+        return self
+
+    # ---- forward
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def forward(self, inputs_ling, input_lengths, inputs_speaker, inputs_style_embedding, inputs_content_embedding,
+                mel_targets=None, output_lengths=None, pitch_targets=None, energy_targets=None, alpha=1.0, cut_flag=True):
+        if mel_targets is not None:
+            raise NotImplementedError("teacher-forced / training branch (mel_targets) is out of scope")
+        if self._blob is None:
+            raise EVError("load_state_dict() must be called before forward()")
+        if self._device_id is None:
+            raise EVError("call .to('cuda:N') first: there is no CPU path")
+        eng = self._ensure_engine()
+        is_torch = hasattr(inputs_ling, "detach")
+
+        def host(x, dt):
+            if hasattr(x, "detach"):
+                x = x.detach().cpu().numpy()
+            return np.ascontiguousarray(np.asarray(x), dtype=dt)
+
+        ling = host(inputs_ling, np.int64)
+        if ling.ndim == 1:
+            ling = ling[None]
+        lengths = host(input_lengths, np.int64).reshape(-1)
+        B, Nmax = ling.shape
+        if lengths.shape[0] != B or lengths.max() > Nmax or lengths.min() <= 0:
+            raise ValueError("input_lengths inconsistent with inputs_ling")
+        if ling.min() < 0 or ling.max() >= self.shapes.n_vocab:
+            raise IndexError("phoneme id out of range")          # nn.Embedding raises IndexError as well
+        spk = host(inputs_speaker, np.int64).reshape(-1)
+        if spk.min() < 0 or spk.max() >= self.shapes.n_speaker:
+            raise IndexError("speaker id out of range")
+        style = host(inputs_style_embedding, np.float32).reshape(B, -1)
+        content = host(inputs_content_embedding, np.float32).reshape(B, -1)
+        packed = np.ascontiguousarray(np.concatenate([ling[b, :lengths[b]] for b in range(B)]))
+        cu = np.zeros(B + 1, np.int32)
+        cu[1:] = np.cumsum(lengths)
+        res = eng.synthesize_raw(B, packed.ctypes.data, cu, spk.ctypes.data, style.ctypes.data, content.ctypes.data,
+                                 float(alpha), 0)
+        T = np.array([res.mel_lens[b] for b in range(B)], np.int64)
+        offs = np.array([res.mel_offsets[b] for b in range(B + 1)], np.int64)
+        up = self.upsample_factor
+        if is_torch:
+            out = self._gather_torch(eng, res, B, Nmax, lengths, cu, T, offs, up)
+        else:
+            out = self._gather_numpy(eng, res, B, Nmax, lengths, cu, T, offs, up)
+        out.update(mel_targets=None, postnet_outputs=None, pitch_targets=None, energy_targets=None, duration_targets=None,
+                   input_lengths=input_lengths, output_lengths=None, log_p_attn=None, bin_loss=None, z_start_idxs=None,
+                   segment_size=self.segment_size)
+        return out
+
+    def _gather_numpy(self, eng, res, B, Nmax, lengths, cu, T, offs, up):
+        r = eng.result_to_numpy(res)
+        Tm = int(T.max())
+        wav = np.zeros((B, 1, Tm * up), np.float32)
+        mel = np.zeros((B, Tm, self.shapes.n_mels), np.float32)
+        dur = np.zeros((B, Nmax), np.int64)
+        pit = np.zeros((B, Nmax), np.float32)
+        ene = np.zeros((B, Nmax), np.float32)
+        for b in range(B):
+            wav[b, 0, :T[b] * up] = r["wav_list"][b]
+            mel[b, :T[b]] = r["mel_list"][b]
+            dur[b, :lengths[b]] = r["durations"][cu[b]:cu[b + 1]]
+            pit[b, :lengths[b]] = r["pitch"][cu[b]:cu[b + 1]]
+            ene[b, :lengths[b]] = r["energy"][cu[b]:cu[b + 1]]
+        return dict(wav_predictions=wav, dec_outputs=mel, log_duration_predictions=dur, pitch_predictions=pit.squeeze(),
+                    energy_predictions=ene.squeeze())
+
+    def _gather_torch(self, eng, res, B, Nmax, lengths, cu, T, offs, up):
+        import torch
+        dev = torch.device("cuda", self._device_id)
+        try:
+            wav_flat = torch.as_tensor(_DevArray(res.wav, (res.total_samples,), "<f4"), device=dev)
+            mel_flat = torch.as_tensor(_DevArray(res.mel, (res.total_frames, self.shapes.n_mels), "<f4"), device=dev)
+            dur_flat = torch.as_tensor(_DevArray(res.durations, (res.total_tokens,), "<i8"), device=dev)
+            pit_flat = torch.as_tensor(_DevArray(res.pitch, (res.total_tokens,), "<f4"), device=dev)
+            ene_flat = torch.as_tensor(_DevArray(res.energy, (res.total_tokens,), "<f4"), device=dev)
+        except Exception:       # no __cuda_array_interface__ support in this torch build: stage through the host
+            r = eng.result_to_numpy(res)
+            wav_flat, mel_flat = torch.from_numpy(r["wav"]).to(dev), torch.from_numpy(r["mel"]).to(dev)
+            dur_flat, pit_flat, ene_flat = (torch.from_numpy(r[k]).to(dev) for k in ("durations", "pitch", "energy"))
+        Tm = int(T.max())
+        if B == 1:               # the reference's only call pattern: plain views + clone, no padding work
+            wav = wav_flat.clone().view(1, 1, -1)
+            mel = mel_flat.clone().view(1, Tm, -1)
+            dur, pit, ene = dur_flat.clone().view(1, -1), pit_flat.clone().view(1, -1), ene_flat.clone().view(1, -1)
+        else:
+            wav = torch.zeros(B, 1, Tm * up, device=dev)
+            mel = torch.zeros(B, Tm, self.shapes.n_mels, device=dev)
+            dur = torch.zeros(B, Nmax, dtype=torch.int64, device=dev)
+            pit, ene = torch.zeros(B, Nmax, device=dev), torch.zeros(B, Nmax, device=dev)
+            for b in range(B):
+                wav[b, 0, :T[b] * up] = wav_flat[offs[b] * up:offs[b + 1] * up]
+                mel[b, :T[b]] = mel_flat[offs[b]:offs[b + 1]]
+                dur[b, :lengths[b]] = dur_flat[cu[b]:cu[b + 1]]
+                pit[b, :lengths[b]] = pit_flat[cu[b]:cu[b + 1]]
+                ene[b, :lengths[b]] = ene_flat[cu[b]:cu[b + 1]]
+        return dict(wav_predictions=wav, dec_outputs=mel, log_duration_predictions=dur, pitch_predictions=pit.squeeze(),
+                    energy_predictions=ene.squeeze())
