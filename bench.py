@@ -139,10 +139,15 @@ def main():
         eng.set_profiling(False)
         f1 = int(res.total_frames)
         voc = stats.get("voc_conv_gemm_f16")
+        traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
+        tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
+        if os.path.exists(tpath) and B == 32 and N == 256:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         if voc and voc["ms"] > 0:
             achieved = VOC_CONV_FLOP_PER_FRAME * f1 / (voc["ms"] * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel="conv_gemm_kernel<f16> (HiFi-GAN convs)", achieved=round(achieved, 2),
-                        peak=PEAK_MFMA_F16, unit="TFLOP/s", frac=round(achieved / PEAK_MFMA_F16, 4), traffic=None,
+                        peak=PEAK_MFMA_F16, unit="TFLOP/s", frac=round(achieved / PEAK_MFMA_F16, 4), traffic=traffic,
+                        traffic_note="HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024 / 77 launches, profiles/latest_hbm_traffic.json",
                         launches=voc["launches"], avg_launch_ms=round(voc["ms"] / voc["launches"], 4),
                         hbm_contract_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc["ms"] * 1e-3) / 1e9, 1),
                         hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc["ms"] * 1e-3) / 1e9 / PEAK_HBM, 4))
