@@ -13,6 +13,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -403,12 +404,15 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                 const int dil = c.rb_dils[j][d];
                 WPTR(w1, char, rb + ".c1." + std::to_string(d) + ".w16"); WPTR(b1, float, rb + ".c1." + std::to_string(d) + ".b");
                 WPTR(w2, char, rb + ".c2." + std::to_string(d) + ".w16"); WPTR(b2, float, rb + ".c2." + std::to_string(d) + ".b");
-                // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
-                p = gemm_defaults();
-                p.dtype = DT_F16; p.A = xcur; p.lda = cout; p.W = w1; p.bias = b1; p.M = rows_out; p.N = cout; p.K = cout;
-                p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
-                p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.out16 = vb.tmp.p; p.ldo = cout;
-                if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
+                const bool fused = (cout == 32) && (k == 3 || k == 7 || k == 11) && !getenv("EV_NO_FUSED_PAIR");
+                if (!fused) {
+                    // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
+                    p = gemm_defaults();
+                    p.dtype = DT_F16; p.A = xcur; p.lda = cout; p.W = w1; p.bias = b1; p.M = rows_out; p.N = cout; p.K = cout;
+                    p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
+                    p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.out16 = vb.tmp.p; p.ldo = cout;
+                    if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
+                }
                 // x = c2(xt) + x  (models.py:54-56)
                 p = gemm_defaults();
                 p.dtype = DT_F16; p.A = vb.tmp.p; p.lda = cout; p.W = w2; p.bias = b2; p.M = rows_out; p.N = cout; p.K = cout;
@@ -430,7 +434,15 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                         if (keep) { p.out32 = (float*)vb.mrf_tap[i].p; p.out32_before_post = 1; }
                     }
                 }
-                if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
+                if (fused) {
+                    // conv1 -> LDS -> conv2 + residual / MRF epilogue in one persistent kernel (ev_gemm.hip)
+                    ResPairParams rp;
+                    memset(&rp, 0, sizeof rp);
+                    rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = w2; rp.M = rows_out; rp.k = k; rp.dil = dil; rp.epi = p;
+                    const double fl = 2.0 * 2.0 * valid_out * cout * (double)cout * k;
+                    KScope ks(h, "voc_resblock_pair_c32", fl, valid_out * cout * 2.0 * 2.0);
+                    launch_resblock_pair_c32(rp, h->stream);
+                } else if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
             }
         }
         prev = vb.nxt[i].p;
@@ -982,6 +994,14 @@ int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* stream) {
     const int es = p.dtype == DT_F16 ? 2 : 4;
     if (p.M % ROW_ALIGN || p.N % 32 || (p.K * es) % 64 || (p.taps - 1) * p.dil > 64) return -2;
     launch_conv_gemm(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* stream) {
+    static_assert(sizeof(ev_res_pair_desc) == sizeof(ResPairParams), "descriptor layout must match ResPairParams");
+    ResPairParams p;
+    memcpy(&p, d, sizeof p);
+    if (p.k != 3 && p.k != 7 && p.k != 11) return -2;
+    launch_resblock_pair_c32(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, const uint8_t* row_valid,

@@ -65,7 +65,8 @@ template <int TC>
 __device__ __forceinline__ constexpr int epi_wave_bytes() { return 32 * epi_pitch<TC>(); }
 
 template <int MT, int NT>
-__device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0) {
+__device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0,
+                                                  int t_end = 0x7fffffff) {
     constexpr int TC = NT * 16;
     constexpr int PITCH = epi_pitch<TC>();
     constexpr int LPR = TC / 8;          // lanes per row (8 channels each)
@@ -96,6 +97,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4
         for (int it = 0; it < 32 / RPI; ++it) {
             const int lr = it * RPI + rr;
             const int t = t0 + pass * 32 + lr;
+            if (t >= t_end) continue;            // rows owned by the next tile (fused pair kernel) or beyond the tensor
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32 + 16);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -357,6 +359,278 @@ static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
         else launch_cfg<TIn, 128, 128, 2, 2>(p, s);
     } else if (p.N % 64 == 0) launch_cfg<TIn, 256, 64, 4, 1>(p, s);
     else launch_cfg<TIn, 256, 32, 4, 1>(p, s);
+}
+
+// =====================================================================================================================
+// Fused ResBlock pair, C = 32 (HiFi-GAN stage 3: 256 samples x 32 channels per mel frame, the HBM-bound end of the vocoder:
+// layer-wise each conv moves 64 B in + 64 B out per sample for 2*32*32*k FLOP).  One persistent block per CU:
+//   * W1 and W2 (k taps x 32 x 32 fp16 each, <= 22.5 KB) are loaded into LDS once per block and stay there; every wave
+//     pulls the current conv's 2*k fragments into registers once per tile, so the tap loop reads only activation fragments;
+//   * a tile = 256 rows of conv1 output = 256 - (k-1) rows of conv2 output; the raw input slab (256 + (k-1)*d rows) of the
+//     NEXT tile is prefetched into registers during the current tile; leaky-relu is applied on conv1's fragments and the
+//     residual add reads the same slab, so x crosses HBM exactly once per pair;
+//   * conv1's bias + leaky-relu + sequence-edge masking happen in registers, xt goes to LDS as fp16, conv2 reads it with
+//     dilation 1, and the residual / MRF epilogue is the same LDS-transposed coalesced epilogue as the GEMM kernel.
+// HBM traffic per pair: read x once (+ the residual re-read, an L2 hit), write once -- vs 5 tensor passes layer-wise.
+template <int K>
+__global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPairParams p) {
+    // 8 waves x 32 rows: two waves per SIMD hide each other's LDS / global latency (one 4-wave block per CU measured 7 us per
+    // tile, dominated by exposed residual loads in the epilogue); the residual and MRF-accumulate rows of a tile are
+    // requested BEFORE conv2 so that they land during its MFMAs.
+    constexpr int C = 32, H2 = (K - 1) / 2, BMO = 256 - 2 * H2, NW = 8;
+    constexpr int XROWS = 384, XTROWS = 272, XCH = XROWS * 4 / 512;
+    constexpr int WBYTES = K * C * 64, XBYTES = XROWS * 64, XTBYTES = XTROWS * 64;
+    constexpr int EPITCH = C * 4 + 16, EBYTES = 32 * EPITCH;          // per-wave transpose scratch: 32 rows x 32 fp32
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* W1s = smem;
+    char* W2s = smem + WBYTES;
+    char* Xa = smem + 2 * WBYTES;            // [2][XROWS][64]
+    char* Xt = Xa + 2 * XBYTES;              // [XTROWS][64]
+    char* Es = Xt + XTBYTES;                 // [NW][EBYTES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int h1 = H2 * p.dil;
+    const long x_pitch = (long)p.ldx * 2;
+    const char* xg = reinterpret_cast<const char*>(p.x);
+    const int ntiles = (p.M + BMO - 1) / BMO;
+    const ConvGemmParams& e = p.epi;
+
+    for (int c = tid; c < K * C * 4; c += 512) {
+        const int row = c >> 2, part = c & 3, tap = row >> 5, co = row & 31;
+        const long off = ((long)(co * K + tap) * C) * 2 + part * 16;
+        *reinterpret_cast<uint4*>(W1s + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w1) + off);
+        *reinterpret_cast<uint4*>(W2s + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w2) + off);
+    }
+    float b1v[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1v[a][q] = p.b1[a * 16 + 4 * fq + q];
+    // coalesced-side mapping of the epilogue: 4 lanes per row (8 channels each), 16 rows per wave-instruction
+    const int er = lane >> 2, eg = lane & 3, eco = eg * 8;
+    float b2v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b2v[q] = e.bias ? e.bias[eco + q] : 0.f;
+
+    uint4 xr0, xr1, xr2 = make_uint4(0, 0, 0, 0);
+    const int xd0 = swz(tid >> 2, tid & 3), xd1 = swz((tid + 512) >> 2, tid & 3), xd2 = swz((tid + 1024) >> 2, tid & 3);
+    static_assert(XCH == 3, "three 16-B chunks per thread");
+#define EV_PAIR_ROW(G) ((G) < -64 ? -64 : ((G) > (long)p.M + 63 ? (long)p.M + 63 : (G)))
+#define EV_PAIR_GLOAD(TILE)                                                                                \
+    {                                                                                                      \
+        const long g0_ = (long)(TILE) * BMO - H2 - h1 + (tid >> 2);                                        \
+        xr0 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_) * x_pitch + (tid & 3) * 16);           \
+        xr1 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_ + 128) * x_pitch + (tid & 3) * 16);     \
+        if ((tid >> 2) < 2 * h1 + 2 * H2)                                                                   \
+            xr2 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_ + 256) * x_pitch + (tid & 3) * 16); \
+    }
+#define EV_PAIR_SSTORE(BUF)                                                                                \
+    {                                                                                                      \
+        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd0) = xr0;                                        \
+        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd1) = xr1;                                        \
+        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd2) = xr2;                                        \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        EV_PAIR_GLOAD(tile)
+        EV_PAIR_SSTORE(0)
+    }
+    __syncthreads();
+    // both convs' weight fragments (2 * k * 2 x 16 B per lane, 176 VGPRs at k = 11) stay in registers for every tile of this
+    // persistent block: re-reading them from LDS per tile cost as much LDS bandwidth as the activation fragments themselves
+    // (k = 11: both sets = 176 VGPRs would spill at 2 waves / SIMD; conv2's set is then re-read from LDS per tile)
+    constexpr bool W2_RESIDENT = (K <= 7);
+    uint4 wf1[K][2], wf2[K][2];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            wf1[t][a] = *reinterpret_cast<const uint4*>(W1s + swz(t * 32 + a * 16 + fr, fq));
+            if constexpr (W2_RESIDENT) wf2[t][a] = *reinterpret_cast<const uint4*>(W2s + swz(t * 32 + a * 16 + fr, fq));
+        }
+    int cur = 0;
+    const int wrow0 = wave * 32 + fr;
+    char* es = Es + wave * EBYTES;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) EV_PAIR_GLOAD(next)
+        const int m0 = tile * BMO;
+        const int t_end = min(m0 + BMO, p.M);
+        f32x4 acc[2][2];
+        // ---------------- conv1 (dilation d): 256 rows, global rows m0 - H2 + r1
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const char* Xb = Xa + cur * XBYTES;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const int r0 = wrow0 + t * p.dil;
+                const char* xp = Xb + r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    // the slab holds RAW x (the residual is taken from it below); leaky_relu(x, .1) of models.py:51 on the fragment
+                    uint4 xf = lrelu_h8(*reinterpret_cast<const uint4*>(xp + b * 16 * 64), 0.1f);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf1[t][a]),
+                                                                           *reinterpret_cast<half8*>(&xf), acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        // bias + leaky-relu + zero outside the utterance (conv2 must see the reference's zero padding) -> Xt (fp16)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r1 = wrow0 + b * 16;
+            const long g = (long)m0 - H2 + r1;
+            const bool valid = g >= 0 && g < p.M && (e.row_valid ? e.row_valid[g >> e.valid_shift] != 0 : true);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                _Float16 hv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[a][b][q] + b1v[a][q];
+                    v = v > 0.f ? v : v * 0.1f;
+                    hv[q] = valid ? (_Float16)v : (_Float16)0.f;
+                }
+                const int co = a * 16 + 4 * fq;
+                *reinterpret_cast<uint2*>(Xt + swz(r1, co >> 3) + (co & 7) * 2) = *reinterpret_cast<uint2*>(hv);
+            }
+        }
+        // request this wave's residual (and MRF accumulate) rows now: they arrive while conv2 runs
+        uint4 resv[2];
+        float4 accin[2][2];
+        bool rowok[2], rowvalid[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = m0 + wave * 32 + it * 16 + er;
+            rowok[it] = t < t_end;
+            const int tc = rowok[it] ? t : (t_end - 1);
+            rowvalid[it] = e.row_valid ? e.row_valid[tc >> e.valid_shift] != 0 : true;
+            // residual x[t] straight from the LDS slab (slab row = H2 + h1 + (t - m0)), no second trip to L2 / HBM
+            resv[it] = *reinterpret_cast<const uint4*>(Xa + cur * XBYTES + swz(H2 + h1 + (tc - m0), eg));
+            if (e.acc32) {
+                const float* ap = e.acc32 + (long)tc * e.ldacc + eco;
+                accin[it][0] = *reinterpret_cast<const float4*>(ap);
+                accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
+            } else {
+                accin[it][0] = accin[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---------------- conv2 (dilation 1): rows m0 + r2, reads Xt rows r2 + t
+        if constexpr (!W2_RESIDENT) {
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf2[t][a] = *reinterpret_cast<const uint4*>(W2s + swz(t * 32 + a * 16 + fr, fq));
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int r0 = wrow0 + t;
+            const char* xp = Xt + r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                uint4 xf = *reinterpret_cast<const uint4*>(xp + b * 16 * 64);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf2[t][a]),
+                                                                       *reinterpret_cast<half8*>(&xf), acc[a][b], 0, 0, 0);
+            }
+        }
+        // ---------------- epilogue: transpose through the wave's scratch, then 16-byte row-contiguous stores
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                *reinterpret_cast<f32x4*>(es + (b * 16 + fr) * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][b];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int lr = it * 16 + er;
+            const int t = m0 + wave * 32 + lr;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (rowvalid[it]) {
+                const __half2* hh = reinterpret_cast<const __half2*>(&resv[it]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float2 f = __half22float2(hh[q]);
+                    v[2 * q] = (v[2 * q] + b2v[2 * q] + f.x) * e.out_scale;
+                    v[2 * q + 1] = (v[2 * q + 1] + b2v[2 * q + 1] + f.y) * e.out_scale;
+                }
+                v[0] += accin[it][0].x; v[1] += accin[it][0].y; v[2] += accin[it][0].z; v[3] += accin[it][0].w;
+                v[4] += accin[it][1].x; v[5] += accin[it][1].y; v[6] += accin[it][1].z; v[7] += accin[it][1].w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+            }
+            if (rowok[it]) {
+                if (e.out32 && e.out32_before_post) {
+                    float* op = e.out32 + (long)t * e.ldo + eco;
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (e.post_lrelu) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * e.post_slope;
+                }
+                if (e.out32 && !e.out32_before_post) {
+                    float* op = e.out32 + (long)t * e.ldo + eco;
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (e.out16) {
+                    uint4 o;
+                    __half2* h = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = __floats2half2_rn(v[2 * q], v[2 * q + 1]);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(e.out16) + (long)t * e.ldo + eco) = o;
+                }
+            }
+        }
+        if (more) EV_PAIR_SSTORE(cur ^ 1)
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef EV_PAIR_GLOAD
+#undef EV_PAIR_SSTORE
+#undef EV_PAIR_ROW
+}
+
+static size_t pair_lds_bytes(int k) { return 2 * (size_t)k * 32 * 64 + 2 * 384 * 64 + 272 * 64 + 8 * 32 * (32 * 4 + 16); }
+
+void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
+        (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(3));
+        (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(7));
+        (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(11));
+    }
+    const int h2 = (p.k - 1) / 2, bmo = 256 - 2 * h2;
+    const int ntiles = (p.M + bmo - 1) / bmo;
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    const size_t lds = pair_lds_bytes(p.k);
+    switch (p.k) {
+        case 3: hipLaunchKernelGGL((resblock_pair_c32_kernel<3>), dim3(grid), dim3(512), lds, s, p); break;
+        case 7: hipLaunchKernelGGL((resblock_pair_c32_kernel<7>), dim3(grid), dim3(512), lds, s, p); break;
+        case 11: hipLaunchKernelGGL((resblock_pair_c32_kernel<11>), dim3(grid), dim3(512), lds, s, p); break;
+        default: break;
+    }
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {

@@ -37,6 +37,20 @@ struct ConvGemmParams {
 };
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
 
+// Fused HiFi-GAN ResBlock1 pair for C = 32 (reference models/hifigan/models.py:50-57, one iteration of the zip loop):
+//     xt = leaky_relu(c1(leaky_relu(x, .1)) + b1, .1);   out = epilogue(c2(xt) + b2 + x)
+// c1 = Conv1d(C, C, k, dilation d), c2 = Conv1d(C, C, k, dilation 1).  Persistent blocks, both weight sets stationary in LDS,
+// the intermediate xt never leaves LDS.  `epi` carries the c2 epilogue in ConvGemmParams form (bias = b2, res = x,
+// out_scale / acc32 / post_lrelu / out16 / out32 / row_valid as for launch_conv_gemm); its GEMM fields are ignored.
+struct ResPairParams {
+    const void* x; int ldx;             // [rows][32] fp16 residual stream; rows [-64, M+64) readable
+    const void* w1; const float* b1;    // [32][k][32] fp16
+    const void* w2;
+    int M, k, dil;
+    ConvGemmParams epi;
+};
+void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s);
+
 // LayerNorm over the channel dim (eps 1e-12, reference modules/encoder.py:112-127), fp32 in.
 // out16/out32 optional; if dot_w != null additionally dot_out[r] = <LN(x[r]), dot_w> + dot_b.
 struct LayerNormParams {

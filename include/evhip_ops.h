@@ -39,6 +39,18 @@ typedef struct ev_conv_gemm_desc {
 
 int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* hip_stream);
 
+/* Fused HiFi-GAN ResBlock1 pair for C = 32: xt = lrelu(c1(lrelu(x)) + b1); out = epi(c2(xt) + b2 + x)
+ * (reference models/hifigan/models.py:50-57).  `epi` uses the ev_conv_gemm_desc fields bias (= b2), res (= x), res_dtype,
+ * ldres, row_valid, valid_shift, out_scale, acc32, ldacc, post_lrelu, post_slope, out16, out32, ldo, out32_before_post. */
+typedef struct ev_res_pair_desc {
+    const void* x; int ldx;
+    const void* w1; const float* b1;
+    const void* w2;
+    int M, k, dil;
+    ev_conv_gemm_desc epi;
+} ev_res_pair_desc;
+int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* hip_stream);
+
 /* LayerNorm(eps) over channels, optional fused Linear(C,1) head (reference modules/encoder.py:112-127,
  * modules/variance.py:29-33,46). */
 int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,

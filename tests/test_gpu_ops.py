@@ -243,3 +243,50 @@ def test_attention_ragged(lib, is_f16):
         att = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(48), dim=-1) @ v
         ref = att.transpose(0, 1).reshape(n, Cc)
         assert _rel(out[o:o + n].float().cpu(), ref) < (1e-3 if is_f16 else 2e-6), (n, is_f16)
+
+
+@pytest.mark.parametrize("k,dil", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5)])
+def test_fused_resblock_pair_c32(lib, k, dil):
+    """conv1(dil) -> leaky-relu -> conv2 + residual in one persistent kernel == the two torch convs of
+    models/hifigan/models.py:50-57, incl. sequence-edge masking of the intermediate and the MRF epilogue."""
+    from emotivoice_amd import _ffi
+    torch.manual_seed(100 + k + dil)
+    M, Cc = 5 * 256, 32
+    full, x = _padded(M, Cc, torch.float16)
+    valid = torch.ones(M // 16, dtype=torch.uint8, device="cuda")
+    valid[:2] = 0
+    valid[30:34] = 0
+    valid[-3:] = 0
+    vrow = valid.repeat_interleave(16).bool()
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x[~vrow] = 0
+    w1 = (torch.randn(Cc, Cc, k, device="cuda") / math.sqrt(Cc * k)).half()
+    w2 = (torch.randn(Cc, Cc, k, device="cuda") / math.sqrt(Cc * k)).half()
+    b1, b2 = torch.randn(Cc, device="cuda") * 0.1, torch.randn(Cc, device="cuda") * 0.1
+    acc = torch.randn(M, Cc, device="cuda")
+    w1g, w2g = w1.permute(0, 2, 1).contiguous(), w2.permute(0, 2, 1).contiguous()
+    out16 = torch.full((M, Cc), 7.0, device="cuda", dtype=torch.float16)
+    out32 = torch.full((M, Cc), 7.0, device="cuda")
+    d = _ffi.ev_res_pair_desc()
+    d.x, d.ldx, d.w1, d.b1, d.w2, d.M, d.k, d.dil = x.data_ptr(), Cc, w1g.data_ptr(), b1.data_ptr(), w2g.data_ptr(), M, k, dil
+    e = d.epi
+    e.bias, e.res, e.res_dtype, e.ldres = b2.data_ptr(), x.data_ptr(), 0, Cc
+    e.row_valid, e.valid_shift = valid.data_ptr(), 4
+    e.out_scale, e.acc32, e.ldacc = 1.0 / 3.0, acc.data_ptr(), Cc
+    e.post_lrelu, e.post_slope, e.out16, e.out32, e.ldo, e.out32_before_post = 1, 0.01, out16.data_ptr(), out32.data_ptr(), Cc, 1
+    torch.cuda.synchronize()
+    assert lib.ev_op_resblock_pair_c32(C.byref(d), None) == 0
+    torch.cuda.synchronize()
+    xin = _lrelu(x.float(), 0.1).half().float()
+    xt = _lrelu(_ref_conv(xin, w1, b1, dil, (k - 1) // 2, k), 0.1)
+    xt[~vrow.cpu()] = 0
+    xt = xt.half().float()                                   # the intermediate lives in LDS as fp16
+    ref = (_ref_conv(xt, w2, b2, 1, (k - 1) // 2, k) + x.float().cpu()) * (1.0 / 3.0) + acc.cpu()
+    ref_post = _lrelu(ref, 0.01)
+    ref[~vrow.cpu()] = 0
+    ref_post[~vrow.cpu()] = 0
+    # (an fp16 ulp of the LDS-resident intermediate may round differently than the torch reference: 1e-4, not 2e-5)
+    assert _rel(out32.cpu(), ref) < 1e-4, (k, dil)
+    assert _rel(out16.float().cpu(), ref_post) < 6e-4
+    assert float(out32[~vrow].abs().max()) == 0.0
