@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--phonemes", type=int, default=256)
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances for the CPU baseline sample (0 = skip)")
     ap.add_argument("--decoder-precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
+    ap.add_argument("--force-device", type=int, default=-1, help="debug: put every rank on this device (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -75,12 +77,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: emotivoice_amd has no CPU fallback")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from emotivoice_amd import _ffi
     from emotivoice_amd.engine import EVEngine

@@ -60,7 +60,8 @@ struct ev_handle {
     // weights
     char* wblob = nullptr; bool wblob_owned = false; size_t wbytes = 0;
     std::map<std::string, WeightEntry> wt;
-    std::map<std::string, float> scalar_cache;   // host copies of 1-element tensors (biases of the Linear(C,1) heads, PE alphas)
+    std::map<std::string, float> scalar_cache;
+    float* pe_dev = nullptr; int pe_cap = 0;     // positional table, extended on demand beyond the packed length   // host copies of 1-element tensors (biases of the Linear(C,1) heads, PE alphas)
     // arena
     char* arena[2] = {nullptr, nullptr}; size_t arena_bytes[2] = {0, 0};   // [0] token-rate phase, [1] frame-rate phase + vocoder
     char* pinned = nullptr; size_t pinned_bytes = 0;
@@ -119,6 +120,8 @@ int parse_blob(ev_handle* h, const char* host_hdr, size_t nbytes) {
     if (16 + (size_t)count * sizeof(BlobEntry) > nbytes) return fail(h, "weight blob: truncated table");
     h->wt.clear();
     h->scalar_cache.clear();
+    if (h->pe_dev) { (void)hipFree(h->pe_dev); h->pe_dev = nullptr; }
+    h->pe_cap = 0;
     for (uint32_t i = 0; i < count; ++i) {
         BlobEntry e;
         memcpy(&e, host_hdr + 16 + (size_t)i * sizeof(BlobEntry), sizeof e);
@@ -155,6 +158,26 @@ int get_scalar(ev_handle* h, const std::string& name, float* v) {
         it = h->scalar_cache.emplace(name, x).first;
     }
     *v = it->second;
+    return 0;
+}
+
+// positional encoding rows [0, need): the packed (torch-exact) table first, longer utterances computed on the device
+int ensure_pe(ev_handle* h, int need) {
+    if (need <= h->pe_cap) return 0;
+    const WeightEntry* pw = W(h, "pe");
+    const WeightEntry* dw = W(h, "pe_div");
+    if (!pw || !dw) return -1;
+    const int C = h->cfg.hidden, packed = (int)pw->dims[0];
+    int cap = std::max(need, std::max(packed, 2 * h->pe_cap));
+    cap = (int)align_up((size_t)cap, 1024);
+    float* nb = nullptr;
+    HIPCHK(h, hipMalloc((void**)&nb, (size_t)cap * C * 4));
+    const int have = std::min(packed, cap);
+    HIPCHK(h, hipMemcpyAsync(nb, pw->ptr, (size_t)have * C * 4, hipMemcpyDeviceToDevice, h->stream));
+    launch_pe_extend(nb, reinterpret_cast<const float*>(dw->ptr), have, cap, C, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->pe_dev) HIPCHK(h, hipFree(h->pe_dev));
+    h->pe_dev = nb; h->pe_cap = cap;
     return 0;
 }
 
@@ -598,6 +621,7 @@ void ev_destroy(ev_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; ++i) if (h->arena[i]) (void)hipFree(h->arena[i]);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->pe_dev) (void)hipFree(h->pe_dev);
     if (h->wblob && h->wblob_owned) (void)hipFree(h->wblob);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
     for (auto& kv : h->region_evt) { (void)hipEventDestroy(kv.second.first); (void)hipEventDestroy(kv.second.second); }
@@ -778,10 +802,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     const int Rt = (int)align_up((size_t)rows, ROW_ALIGN);
     h->Rt = Rt;
     if ((flags & EV_FLAG_FORCED_DURATIONS) && (int64_t)h->forced_dur.size() != NT) return fail(h, "forced durations: expected %d values", NT);
-    WPTR(pe, float, "pe");
-    const WeightEntry* pew = W(h, "pe");
-    const int pe_len = (int)pew->dims[0];
-    if (max_tok > pe_len) return fail(h, "utterance longer than the packed positional table (%d > %d)", max_tok, pe_len);
+    if (ensure_pe(h, max_tok)) return -1;
 
     // ---------------- phase 1: token-rate arena
     struct TokBufs {
@@ -840,7 +861,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     float alphas[2];
     if (get_scalar(h, "enc.alpha", &alphas[0]) || get_scalar(h, "dec.alpha", &alphas[1])) return -1;
     { KScope ks(h, "embed_pe", 0, (double)NT * C * 12.0);
-      launch_embed_pe(tb.d_ling, h->d_cu, h->d_tok_seq, h->d_tok_pos, tok_emb, pe, alphas[0], (float*)tb.x.p, keep ? (float*)tb.tokemb_tap.p : nullptr, Rt, C, h->stream); }
+      launch_embed_pe(tb.d_ling, h->d_cu, h->d_tok_seq, h->d_tok_pos, tok_emb, h->pe_dev, alphas[0], (float*)tb.x.p, keep ? (float*)tb.tokemb_tap.p : nullptr, Rt, C, h->stream); }
     if (run_stack(h, "enc", c.enc_layers, DT_F32, trc, tb.x, tb.hb, tb.qkv, tb.ctx, tb.ffn, tb.y, nullptr, keep ? &tb.ltaps : nullptr)) return -1;
     region_end(h, "encoder");
     region_begin(h, "variance");
@@ -876,7 +897,8 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         if (h->mel_lens[b] <= 0) return fail(h, "utterance %d produced %d mel frames", b, h->mel_lens[b]);
         max_frames = std::max(max_frames, h->mel_lens[b]);
     }
-    if (max_frames > pe_len) return fail(h, "utterance longer than the packed positional table (%d frames > %d)", max_frames, pe_len);
+    if (ensure_pe(h, max_frames)) return -1;
+    const float* pe = h->pe_dev;
 
     // ---------------- phase 2: frame-rate arena (placed after the token arena)
     struct FrmBufs { Buf x, hb, qkv, ctx, ffn, y, mel32, mel16, up_tap, y_tap; std::vector<Buf> ltaps; float* d_mel; float* d_wav; int16_t* d_i16; } fb;

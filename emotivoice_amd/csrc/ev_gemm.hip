@@ -354,6 +354,10 @@ static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
         static const char* force = getenv("EV_GEMM_TILE");            // "128" / "256": A/B switch for tools/bench_gemm.py
         const int steps = (p.K * (int)sizeof(TIn) / 64) * p.taps;
         bool big = steps >= 28 || p.N >= 512;
+        // few tiles: fill the 256 CUs first.  The fp32 kernel is MFMA-rate bound (1/16 of fp16), weight traffic is irrelevant
+        // there, so it only takes the big tile when there are plenty of them.
+        const long tiles256 = (long)(p.M / 256) * (p.N / 128);
+        if (tiles256 < (sizeof(TIn) == 4 ? 2048 : 256)) big = false;
         if (force) big = force[0] == '2';
         if (big) launch_cfg<TIn, 256, 128, 2, 2>(p, s);
         else launch_cfg<TIn, 128, 128, 2, 2>(p, s);

@@ -112,6 +112,9 @@ void launch_pack_rows(const void* src, int dtype, int ld, int C, const int64_t* 
                       const int64_t* seq_out_off /* per utterance packed offset (rows) */, const int32_t* seq_rows, int B,
                       int64_t max_rows, float* dst, hipStream_t s);
 
+// rows [row0, row1) of the sinusoid table: pe[t][2i] = sin(t * div[i]), pe[t][2i+1] = cos(t * div[i]) (encoder.py:216-237,
+// which auto-extends its table the same way for inputs longer than max_len)
+void launch_pe_extend(float* pe, const float* div, int row0, int row1, int C, hipStream_t s);
 void launch_wav_to_i16(const float* wav, int16_t* out, int64_t n, hipStream_t s);
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 

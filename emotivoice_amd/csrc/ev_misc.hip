@@ -728,6 +728,21 @@ void launch_wav_to_i16(const float* wav, int16_t* out, int64_t n, hipStream_t s)
     hipLaunchKernelGGL(wav_to_i16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, wav, out, (long)n);
 }
 
+__global__ __launch_bounds__(256) void pe_extend_kernel(float* pe, const float* div, int row0, int rows, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int half = C / 2;
+    if (idx >= (long)rows * half) return;
+    const int t = row0 + (int)(idx / half), i = (int)(idx % half);
+    const float ang = (float)t * div[i];
+    pe[(long)t * C + 2 * i] = sinf(ang);
+    pe[(long)t * C + 2 * i + 1] = cosf(ang);
+}
+void launch_pe_extend(float* pe, const float* div, int row0, int row1, int C, hipStream_t s) {
+    const long n = (long)(row1 - row0) * (C / 2);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pe_extend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pe, div, row0, row1 - row0, C);
+}
+
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, 0, bytes, s); }
 
 }  // namespace ev

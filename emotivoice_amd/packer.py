@@ -96,6 +96,15 @@ def sinusoid_table(length: int, d: int) -> np.ndarray:
     return pe.numpy()
 
 
+def _pe_div_term(d: int) -> np.ndarray:
+    """div_term of modules/encoder.py:224-227 with the reference's fp32 op order (table extension on the device)."""
+    import math
+
+    import torch
+
+    return torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d)).numpy()
+
+
 class _Blob:
     def __init__(self):
         self.items = []
@@ -149,6 +158,7 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
     f32 = lambda k: _np(sd[k]).astype(np.float32)  # noqa: E731
 
     b.add("pe", sinusoid_table(pe_len, H), DT_F32)
+    b.add("pe_div", _pe_div_term(H), DT_F32)       # lets the engine extend the table on the device for longer utterances
     b.add("tok_emb", f32("am.src_word_emb.weight"), DT_F32)
     b.add("spk_emb", f32("am.spk_tokenizer.weight"), DT_F32)
     for short, pre, nl in (("enc", "am.encoder", s.enc_layers), ("dec", "am.decoder", s.dec_layers)):

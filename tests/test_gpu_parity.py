@@ -245,3 +245,67 @@ def test_config2_shape_properties(gpu):
     e = rel_l2(last, ref["wav_predictions"].numpy())
     _report("config2_utt31_wav", e)
     assert e < TOL_OUT
+
+
+def test_config3_ragged_256_properties(gpu):
+    """BASELINE configs[2] at full size: batch 256, lengths 64 + (i*7919 mod 449), speakers i mod 2000 (length-regulator
+    ragged stress).  Size-independent properties: per-utterance lengths consistent (frames = sum of durations, samples =
+    256 * frames), bounded finite audio, shortest / longest / last utterance bit-identical to stand-alone synthesis, and two
+    utterances against the CPU oracle."""
+    from oracle import synth_inputs
+    eng = _engine("parity", "f16", keep=False)
+    lens = [64 + (i * 7919) % 449 for i in range(256)]
+    utts = synth_inputs(3, lens, [i % 2000 for i in range(256)])
+    out = eng.synthesize(utts)
+    cu = out["cu_seqlens"]
+    dsum = np.array([out["durations"][cu[b]:cu[b + 1]].sum() for b in range(256)])
+    assert np.array_equal(dsum, out["mel_lens"]) and (out["durations"] >= 0).all()
+    assert out["wav"].shape[0] == 256 * int(out["mel_lens"].sum()) and out["mel"].shape == (int(out["mel_lens"].sum()), 80)
+    assert np.isfinite(out["wav"]).all() and np.abs(out["wav"]).max() <= 1.0 and np.isfinite(out["mel"]).all()
+    picks = [int(np.argmin(lens)), int(np.argmax(lens)), 255]
+    keep = {b: (out["wav_list"][b].copy(), out["mel_list"][b].copy()) for b in picks}
+    for b in picks:
+        solo = eng.synthesize([utts[b]])
+        assert np.array_equal(solo["wav"], keep[b][0]) and np.array_equal(solo["mel"], keep[b][1]), b
+    errs = {}
+    for b in (picks[0], 17):
+        ref = _oracle("parity", utts[b])
+        w = eng.synthesize([utts[b]])
+        near = _near_boundary(ref["log_dur_raw"].numpy())
+        assert np.array_equal(w["durations"][~near], ref["log_duration_predictions"].numpy()[~near])
+        if np.array_equal(w["durations"], ref["log_duration_predictions"].numpy()):
+            errs[b] = rel_l2(w["wav"], ref["wav_predictions"].numpy())
+            assert errs[b] < TOL_OUT
+    _report("config3", {str(k): v for k, v in errs.items()})
+
+
+def test_config5_vocoder_only_fp16_properties(gpu):
+    """BASELINE configs[4] per-GPU share: 128 pre-computed 80 x 1024 fp16 mels through ev_vocoder.  Linearity does not hold
+    for a GAN vocoder; the size-independent properties are: exact lengths, bounded finite audio, every mel's waveform
+    bit-identical to the same mel vocoded alone (no cross-utterance leakage at any of the 4 upsampling stages)."""
+    eng = _engine("parity", "f16", keep=False)
+    rng = np.random.default_rng(9)
+    base = (1.25 * rng.standard_normal((8, 80, 1024)) + 0.08).astype(np.float16)
+    mels = [base[i % 8] for i in range(128)]
+    out = eng.vocoder(mels)
+    assert out["wav"].shape[0] == 128 * 1024 * 256 and np.isfinite(out["wav"]).all() and np.abs(out["wav"]).max() <= 1.0
+    first = [out["wav_list"][i].copy() for i in range(8)]
+    for i in range(8, 128):
+        assert np.array_equal(out["wav_list"][i], first[i % 8]), i          # identical mels -> identical audio anywhere in the batch
+    solo = eng.vocoder([mels[3]])
+    assert np.array_equal(solo["wav"], first[3])
+
+
+def test_long_utterance_extends_positional_table(gpu):
+    """Utterances longer than the packed sinusoid table (the reference auto-extends its table, encoder.py:216-237):
+    forced durations of 12 frames x 400 phonemes = 4800 frames > 4096."""
+    from oracle import synth_inputs
+    eng = _engine("parity", "f16", keep=False)
+    utt = synth_inputs(71, [400], [11])[0]
+    dur = np.full(400, 12, np.int64)
+    ref = _oracle("parity", utt, durations=torch.from_numpy(dur))
+    out = eng.synthesize([utt], forced_durations=dur, vocoder=False)
+    assert int(out["mel_lens"][0]) == 4800
+    e = rel_l2(out["mel"], ref["dec_outputs"].numpy())
+    _report("long_utt_mel", e)
+    assert e < TOL_OUT
