@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work per mel frame (SURVEY.md section 8(d) / BASELINE.md section 3)
 VOC_CONV_FLOP_PER_FRAME = 614.105e6 - 0.115e6      # every Conv1d/ConvTranspose1d of the generator except conv_post
+VOC_STAGE3_RB_FLOP_PER_FRAME = (9.437 + 22.020 + 34.603) * 1e6   # stage-3 ResBlocks (C = 32): run by the fused pair kernel
 VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 AM_FLOP_PER_UTT = 51.43e9
@@ -151,15 +152,30 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
         if os.path.exists(tpath) and B == 32 and N == 256:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        pair = stats.get("voc_resblock_pair_c32")
         if voc and voc["ms"] > 0:
-            achieved = VOC_CONV_FLOP_PER_FRAME * f1 / (voc["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="conv_gemm_kernel<f16> (HiFi-GAN convs)", achieved=round(achieved, 2),
-                        peak=PEAK_MFMA_F16, unit="TFLOP/s", frac=round(achieved / PEAK_MFMA_F16, 4), traffic=traffic,
-                        traffic_note="HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024 / 77 launches, profiles/latest_hbm_traffic.json",
+            # algorithmic FLOPs of what THIS kernel family executed: all generator convs minus the stage-3 ResBlocks when
+            # those ran in the fused pair kernel
+            gemm_flop = VOC_CONV_FLOP_PER_FRAME - (VOC_STAGE3_RB_FLOP_PER_FRAME if pair else 0.0)
+            achieved = gemm_flop * f1 / (voc["ms"] * 1e-3) / 1e12
+            voc_ms = voc["ms"] + (pair["ms"] if pair else 0.0)
+            roof = dict(bound="mfma", kernel="conv_gemm_kernel<f16> (HiFi-GAN Conv1d/ConvTranspose1d, stages 0-2 + conv_pre + ups)",
+                        achieved=round(achieved, 2), peak=PEAK_MFMA_F16, unit="TFLOP/s", frac=round(achieved / PEAK_MFMA_F16, 4),
+                        traffic=traffic,
+                        traffic_note="HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json",
                         launches=voc["launches"], avg_launch_ms=round(voc["ms"] / voc["launches"], 4),
-                        hbm_contract_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc["ms"] * 1e-3) / 1e9, 1),
-                        hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc["ms"] * 1e-3) / 1e9 / PEAK_HBM, 4))
+                        algorithmic_flop_per_launch=round(gemm_flop * f1 / voc["launches"], 1),
+                        all_vocoder_convs=dict(ms=round(voc_ms, 3), mfma_TFLOPs=round(VOC_CONV_FLOP_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e12, 2),
+                                               hbm_contract_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9, 1),
+                                               hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4)))
+            if pair:
+                roof["fused_pair_kernel"] = dict(ms=round(pair["ms"], 3), launches=pair["launches"],
+                                                 mfma_TFLOPs=round(VOC_STAGE3_RB_FLOP_PER_FRAME * f1 / (pair["ms"] * 1e-3) / 1e12, 2))
         dec = stats.get("dec_f16_gemm") or stats.get("dec_f32_gemm")
+        if roof is not None and dec and "decoder" in stages:
+            roof["mel_decoder"] = dict(ms=round(stages["decoder"], 3),
+                                       mfma_TFLOPs=round(DEC_FLOP_PER_UTT_1024 * B / (stages["decoder"] * 1e-3) / 1e12, 2),
+                                       mfma_frac=round(DEC_FLOP_PER_UTT_1024 * B / (stages["decoder"] * 1e-3) / 1e12 / PEAK_MFMA_F16, 4))
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in stats.items()}
     if rank != 0:
         if dist is not None:

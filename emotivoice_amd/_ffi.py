@@ -52,7 +52,7 @@ class ev_conv_gemm_desc(C.Structure):
         ("pro_slope", C.c_float), ("res", C.c_void_p), ("res_dtype", C.c_int), ("ldres", C.c_int),
         ("out_scale", C.c_float), ("acc32", C.c_void_p), ("ldacc", C.c_int), ("post_lrelu", C.c_int),
         ("post_slope", C.c_float), ("out16", C.c_void_p), ("out32", C.c_void_p), ("ldo", C.c_int),
-        ("out32_before_post", C.c_int), ("debug_flags", C.c_int),
+        ("out32_before_post", C.c_int), ("reserved0", C.c_int),
     ]
 
 

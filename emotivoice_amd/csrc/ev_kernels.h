@@ -32,8 +32,7 @@ struct ConvGemmParams {
     int post_lrelu; float post_slope;
     void* out16; float* out32; int ldo;          // either / both outputs
     int out32_before_post;                       // out32 receives the value BEFORE post_lrelu (stage taps)
-    int debug_flags;                             // ablation (tools/bench_gemm.py only): 1 no global loads in loop, 2 no MFMA,
-                                                 // 4 no LDS fragment reads, 8 no epilogue, 16 no barrier
+    int reserved0;                               // (was: ablation switches used while tuning)
 };
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
 

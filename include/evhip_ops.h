@@ -34,7 +34,7 @@ typedef struct ev_conv_gemm_desc {
     int post_lrelu; float post_slope;
     void* out16; float* out32; int ldo;
     int out32_before_post;
-    int debug_flags;           /* ablation switches for tools/bench_gemm.py; 0 in production */
+    int reserved0;
 } ev_conv_gemm_desc;
 
 int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* hip_stream);

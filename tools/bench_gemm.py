@@ -34,6 +34,7 @@ SHAPES = {
     "dec_qkv": (0, RF, 384, 1152, 1, 1, False, False),
     "dec_out": (0, RF, 384, 384, 1, 1, True, False),
     "dec_ffn1": (0, RF, 384, 1536, 3, 1, False, False),
+    "dec_ffn1_gelu": (0, RF, 384, 1536, 3, 1, False, "gelu"),
     "dec_ffn2": (0, RF, 1536, 384, 3, 1, True, False),
     "enc_ffn1_f32": (1, 8448, 384, 1536, 3, 1, False, False),
     "enc_ffn2_f32": (1, 8448, 1536, 384, 3, 1, True, False),
@@ -44,7 +45,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--dbg", default="0", help="comma list of debug_flags values to sweep")
     args = ap.parse_args()
     lib = _ffi.lib()
     for name in args.shapes.split(","):
@@ -61,7 +61,9 @@ def main():
         d.A, d.lda, d.W, d.bias = a[64:].data_ptr(), K, w.data_ptr(), bias.data_ptr()
         d.M, d.N, d.K, d.taps, d.dil, d.center = M, N, K, taps, dil, (taps - 1) // 2
         d.out_scale = 1.0
-        if pro:
+        if pro == "gelu":
+            d.act = 2
+        elif pro:
             d.pro_lrelu, d.pro_slope, d.act, d.act_slope = 1, 0.1, 3, 0.1
         if r is not None:
             d.res, d.res_dtype, d.ldres = r.data_ptr(), dtype, N
@@ -70,8 +72,7 @@ def main():
         else:
             d.out32 = out.data_ptr()
         d.ldo = N
-        for dbg in [int(x) for x in args.dbg.split(",")]:
-            d.debug_flags = dbg
+        for dbg in [0]:
             for _ in range(2):
                 lib.ev_op_conv_gemm(C.byref(d), None)
             torch.cuda.synchronize()
