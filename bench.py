@@ -177,6 +177,23 @@ def main():
                                        mfma_TFLOPs=round(DEC_FLOP_PER_UTT_1024 * B / (stages["decoder"] * 1e-3) / 1e12, 2),
                                        mfma_frac=round(DEC_FLOP_PER_UTT_1024 * B / (stages["decoder"] * 1e-3) / 1e12 / PEAK_MFMA_F16, 4))
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in stats.items()}
+    # single-utterance latency (the reference's own call pattern, B = 1; BASELINE configs[0] is 64 phonemes): host-to-host
+    # wall time of one ev_synthesize with host inputs, best of 20
+    lat = {}
+    if rank == 0:
+        for nph in (64, 256):
+            u = synth_inputs(99, [nph], None)[0]
+            ling1 = np.ascontiguousarray(u["ling"]); cu1 = np.array([0, nph], np.int32)
+            spk1 = np.zeros(1, np.int64); st1 = np.ascontiguousarray(u["style"]); ct1 = np.ascontiguousarray(u["content"])
+            best = 1e9
+            for it in range(23):
+                t1 = time.perf_counter()
+                r1 = eng.synthesize_raw(1, ling1.ctypes.data, cu1, spk1.ctypes.data, st1.ctypes.data, ct1.ctypes.data, 1.0, 0)
+                dtl = time.perf_counter() - t1
+                if it >= 3:
+                    best = min(best, dtl)
+            lat["b1_%dph_ms" % nph] = round(best * 1e3, 3)
+            lat["b1_%dph_x_realtime" % nph] = round(int(r1.total_frames) * 256 / 16000 / best, 1)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -194,7 +211,7 @@ def main():
                                "4 frames/phoneme" % (B, N), "global_batch": B * world, "phonemes": N,
                    "frames_per_utt": int(frames / args.steps / world / B), "parallelism": "utterance-sharded x%d" % world,
                    "token_rate_precision": "f32", "frame_rate_precision": args.decoder_precision},
-        "roofline": roof, "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "kernels_ms": kernels,
+        "latency": lat, "roofline": roof, "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "kernels_ms": kernels,
     }
     if world == 1 and args.cpu_utts > 0:
         line["cpu_baseline"] = cpu_baseline(args.cpu_utts, N)

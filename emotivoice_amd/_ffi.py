@@ -25,7 +25,7 @@ class ev_config(C.Structure):
         ("up_rates", C.c_int32 * 8), ("up_kernels", C.c_int32 * 8), ("up_init_ch", C.c_int32), ("n_rb", C.c_int32),
         ("rb_kernels", C.c_int32 * 8), ("rb_dils", (C.c_int32 * 4) * 8), ("n_rb_dils", C.c_int32),
         ("sample_rate", C.c_int32), ("decoder_precision", C.c_int32), ("keep_stages", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("token_rate_split", C.c_int32), ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -45,7 +45,7 @@ class ev_kernel_stat(C.Structure):
 
 class ev_conv_gemm_desc(C.Structure):
     _fields_ = [
-        ("dtype", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("dtype", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("W_lo", C.c_void_p), ("bias", C.c_void_p),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("taps", C.c_int), ("dil", C.c_int), ("center", C.c_int),
         ("row_valid", C.c_void_p), ("valid_shift", C.c_int), ("row_seq", C.c_void_p), ("seq_bias", C.c_void_p),
         ("ld_seq_bias", C.c_int), ("act", C.c_int), ("act_slope", C.c_float), ("pro_lrelu", C.c_int),

@@ -274,6 +274,7 @@ void profiling_collect(ev_handle* h) {
 int check_gemm(ev_handle* h, const ConvGemmParams& p) {
     const int es = p.dtype == DT_F16 ? 2 : 4;
     if (p.M % ROW_ALIGN) return fail(h, "gemm: M=%d not a multiple of %d", p.M, ROW_ALIGN);
+    if (p.dtype == DT_F32S && (p.K % 32 || p.N % 64 || !p.W_lo || p.pro_lrelu)) return fail(h, "gemm: bad split-precision call");
     if (p.N % 32) return fail(h, "gemm: N=%d not a multiple of 32", p.N);
     if ((p.K * es) % 64) return fail(h, "gemm: K=%d not a multiple of %d", p.K, 64 / es);
     if ((p.taps - 1) * p.dil > 64) return fail(h, "gemm: conv span %d > 64", (p.taps - 1) * p.dil);
@@ -297,6 +298,21 @@ ConvGemmParams gemm_defaults() {
     memset(&p, 0, sizeof p);
     p.taps = 1; p.dil = 1; p.center = 0; p.out_scale = 1.0f;
     return p;
+}
+
+// token-rate (fp32) GEMM operands: exact fp32 MFMA or the hi/lo split pair (cfg.token_rate_split)
+int tok_weights(ev_handle* h, const std::string& base /* e.g. "enc.0.qkv.w" */, ConvGemmParams& p) {
+    if (h->cfg.token_rate_split && base.compare(0, 4, "dec.") != 0) {
+        const WeightEntry* hi = W(h, base + "32h");
+        const WeightEntry* lo = W(h, base + "32l");
+        if (!hi || !lo) return -1;
+        p.dtype = DT_F32S; p.W = hi->ptr; p.W_lo = lo->ptr;
+    } else {
+        const WeightEntry* w = W(h, base + "32");
+        if (!w) return -1;
+        p.dtype = DT_F32; p.W = w->ptr; p.W_lo = nullptr;
+    }
+    return 0;
 }
 
 struct RowCtx {     // one row layout (token rate or frame rate)
@@ -328,6 +344,7 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         ConvGemmParams p = gemm_defaults();
         p.dtype = prec; p.A = hbuf.p; p.lda = C; p.W = wqkv; p.bias = bqkv; p.M = rc.R; p.N = 3 * C; p.K = C;
         p.row_valid = rc.valid; p.ldo = 3 * C;
+        if (prec == DT_F32 && tok_weights(h, lp + ".qkv.w", p)) return -1;
         if (prec == DT_F16) p.out16 = qkv.p; else p.out32 = (float*)qkv.p;
         if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         AttnParams ap{};
@@ -337,17 +354,20 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         p = gemm_defaults();
         p.dtype = prec; p.A = ctx.p; p.lda = C; p.W = wout; p.bias = bout; p.M = rc.R; p.N = C; p.K = C;
         p.row_valid = rc.valid; p.res = x.p; p.res_dtype = DT_F32; p.ldres = C; p.out32 = (float*)x.p; p.ldo = C;
+        if (prec == DT_F32 && tok_weights(h, lp + ".out.w", p)) return -1;
         if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         ln.gamma = g2; ln.beta = b2;
         { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
         p = gemm_defaults();
         p.dtype = prec; p.A = hbuf.p; p.lda = C; p.W = wf1; p.bias = bf1; p.M = rc.R; p.N = F; p.K = C; p.taps = kf; p.center = (kf - 1) / 2;
         p.row_valid = rc.valid; p.act = ACT_GELU; p.ldo = F;
+        if (prec == DT_F32 && tok_weights(h, lp + ".ffn1.w", p)) return -1;
         if (prec == DT_F16) p.out16 = ffn.p; else p.out32 = (float*)ffn.p;
         if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         p = gemm_defaults();
         p.dtype = prec; p.A = ffn.p; p.lda = F; p.W = wf2; p.bias = bf2; p.M = rc.R; p.N = C; p.K = F; p.taps = kf; p.center = (kf - 1) / 2;
         p.row_valid = rc.valid; p.res = x.p; p.res_dtype = DT_F32; p.ldres = C; p.out32 = (float*)x.p; p.ldo = C;
+        if (prec == DT_F32 && tok_weights(h, lp + ".ffn2.w", p)) return -1;
         if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         if (layer_taps) HIPCHK(h, hipMemcpyAsync((*layer_taps)[i].p, x.p, x.bytes, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -372,6 +392,7 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
         ConvGemmParams p = gemm_defaults();
         p.dtype = DT_F32; p.A = cur; p.lda = C; p.W = w; p.bias = b; p.M = rc.R; p.N = C; p.K = C; p.taps = k; p.center = (k - 1) / 2;
         p.row_valid = rc.valid; p.act = ACT_RELU; p.out32 = (float*)t1.p; p.ldo = C;
+        if (tok_weights(h, lp + ".conv.w", p)) return -1;
         if (gemm(h, "variance_f32_gemm", p, rc.n_valid)) return -1;
         LayerNormParams ln{};
         ln.x = (const float*)t1.p; ln.ldx = C; ln.rows = rc.R; ln.C = C; ln.gamma = g; ln.beta = be; ln.eps = 1e-12f;
@@ -587,7 +608,7 @@ void ev_default_config(ev_config* c) {
     for (int i = 0; i < 4; ++i) { c->up_rates[i] = ur[i]; c->up_kernels[i] = uk[i]; }
     c->up_init_ch = 512; c->n_rb = 3; c->n_rb_dils = 3;
     for (int j = 0; j < 3; ++j) { c->rb_kernels[j] = rk[j]; for (int d = 0; d < 3; ++d) c->rb_dils[j][d] = rd[d]; }
-    c->sample_rate = 16000; c->decoder_precision = EV_PREC_F16; c->keep_stages = 0;
+    c->sample_rate = 16000; c->decoder_precision = EV_PREC_F16; c->keep_stages = 0; c->token_rate_split = 1;
 }
 
 const char* ev_last_error(ev_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -873,6 +894,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         ConvGemmParams p = gemm_defaults();
         p.dtype = DT_F32; p.A = tb.y.p; p.lda = C; p.W = wproj; p.M = Rt; p.N = C; p.K = C; p.row_valid = h->d_tok_valid;
         p.row_seq = h->d_tok_seq; p.seq_bias = tb.d_u; p.ld_seq_bias = C; p.out32 = (float*)tb.xp.p; p.ldo = C;
+        if (tok_weights(h, "proj.w", p)) return -1;
         if (gemm(h, "variance_f32_gemm", p, NT)) return -1;
     }
     if (run_predictor(h, "pitch", c.pitch_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.pitch.p)) return -1;
@@ -1015,6 +1037,7 @@ int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* stream) {
     memcpy(&p, d, sizeof p);
     const int es = p.dtype == DT_F16 ? 2 : 4;
     if (p.M % ROW_ALIGN || p.N % 32 || (p.K * es) % 64 || (p.taps - 1) * p.dil > 64) return -2;
+    if (p.dtype == DT_F32S && (p.K % 32 || p.N % 64 || !p.W_lo)) return -2;
     launch_conv_gemm(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -366,6 +366,170 @@ static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
 }
 
 // =====================================================================================================================
+// Split-precision GEMM for the fp32 token-rate path (text encoder, embed_projection1, variance / duration predictors).
+// The fp32-input MFMA runs at 1/16 of the fp16 rate; instead every fp32 operand is written as
+//        x = x_hi + 2^-11 * x_lo,   x_hi = fp16(x),  x_lo = fp16((x - x_hi) * 2^11)        (weights: split once by the packer)
+// and  x*w = x_hi*w_hi + 2^-11 (x_hi*w_lo + x_lo*w_hi) + O(2^-22 |x w|):  three fp16 MFMAs (fp16 products are exact in fp32,
+// accumulation is fp32) into two accumulators.  The dropped term and the representation error are 2^-22 relative, the same
+// order as fp32 rounding itself, so the duration path keeps its fp32-level agreement with the reference (tests hold the
+// token-rate taps to 1e-4 and the durations bit-exact) at ~4x the speed.  The 2^11 scaling keeps the low parts out of fp16's
+// subnormal range.  Activations are split while staging (fp32 global -> two fp16 LDS slabs).
+// Tile 128 x 64, 4 waves (64 x 32 per wave), one K step = 32 elements, register prefetch of the next step's tiles.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmParams p) {
+    constexpr int TT = 64, TC = BN / 2, MT = 4, NT = TC / 16;
+    constexpr int SLAB = BM + MAX_SPAN, XCH = SLAB * 4 / 256, WCH = BN * 4 / 256;
+    constexpr int XBUF = SLAB * 64, WBUF = BN * 64;
+    static_assert(BM == 128 && WCH == 1 && XCH == 3, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xh = smem;                    // [2][SLAB][64]  hi parts
+    char* Xl = Xh + 2 * XBUF;           // [2][SLAB][64]  lo parts
+    char* Wh = Xl + 2 * XBUF;           // [2][BN][64]
+    char* Wl = Wh + 2 * WBUF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave >> 1, wc = wave & 1;
+    const int nN = p.N / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (bid / nN) * BM, n0 = (bid % nN) * BN;
+    const int taps = p.taps, nkc = p.K >> 5, steps = nkc * taps;
+    const long a_pitch = (long)p.lda * 4;
+    const long w_tap_pitch = (long)p.K * 2, w_row_pitch = w_tap_pitch * taps;
+
+    // staging: chunk c -> slab row c >> 2, 16-byte fp16 part c & 3  <-  32 bytes (8 floats) of the fp32 row
+    const char* xsrc[XCH]; int xdst[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + i * 256, r = c >> 2, part = c & 3;
+        xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + r) * a_pitch + part * 32;
+        xdst[i] = swz(r, part);
+    }
+    const int wr_ = tid >> 2, wp_ = tid & 3;
+    const long wsrc_off = (long)(n0 + wr_) * w_row_pitch + wp_ * 16;
+    const int wdst = swz(wr_, wp_);
+    const char* Whg = reinterpret_cast<const char*>(p.W);
+    const char* Wlg = reinterpret_cast<const char*>(p.W_lo);
+
+    float4 xa0, xb0, xa1, xb1, xa2, xb2;      // 3 chunks x 8 floats
+    uint4 whr, wlr;
+#define EV_S_GLOAD_X(KC)                                                                         \
+    {                                                                                            \
+        xa0 = *reinterpret_cast<const float4*>(xsrc[0] + (long)(KC) * 128);                      \
+        xb0 = *reinterpret_cast<const float4*>(xsrc[0] + (long)(KC) * 128 + 16);                 \
+        xa1 = *reinterpret_cast<const float4*>(xsrc[1] + (long)(KC) * 128);                      \
+        xb1 = *reinterpret_cast<const float4*>(xsrc[1] + (long)(KC) * 128 + 16);                 \
+        xa2 = *reinterpret_cast<const float4*>(xsrc[2] + (long)(KC) * 128);                      \
+        xb2 = *reinterpret_cast<const float4*>(xsrc[2] + (long)(KC) * 128 + 16);                 \
+    }
+#define EV_S_SPLIT_STORE(XA, XB, DST, BUF)                                                       \
+    {                                                                                            \
+        const float f_[8] = {XA.x, XA.y, XA.z, XA.w, XB.x, XB.y, XB.z, XB.w};                    \
+        half8 hi_, lo_;                                                                          \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                          \
+            const _Float16 h_ = (_Float16)f_[e];                                                 \
+            hi_[e] = h_;                                                                         \
+            lo_[e] = (_Float16)((f_[e] - (float)h_) * 2048.0f);                                  \
+        }                                                                                        \
+        *reinterpret_cast<half8*>(Xh + (BUF) * XBUF + (DST)) = hi_;                              \
+        *reinterpret_cast<half8*>(Xl + (BUF) * XBUF + (DST)) = lo_;                              \
+    }
+#define EV_S_SSTORE_X(BUF)                                                                       \
+    {                                                                                            \
+        EV_S_SPLIT_STORE(xa0, xb0, xdst[0], BUF)                                                 \
+        EV_S_SPLIT_STORE(xa1, xb1, xdst[1], BUF)                                                 \
+        EV_S_SPLIT_STORE(xa2, xb2, xdst[2], BUF)                                                 \
+    }
+#define EV_S_GLOAD_W(KC, TAP)                                                                    \
+    {                                                                                            \
+        const long o_ = wsrc_off + (long)(TAP) * w_tap_pitch + (long)(KC) * 64;                  \
+        whr = *reinterpret_cast<const uint4*>(Whg + o_);                                         \
+        wlr = *reinterpret_cast<const uint4*>(Wlg + o_);                                         \
+    }
+#define EV_S_SSTORE_W(BUF)                                                                       \
+    {                                                                                            \
+        *reinterpret_cast<uint4*>(Wh + (BUF) * WBUF + wdst) = whr;                               \
+        *reinterpret_cast<uint4*>(Wl + (BUF) * WBUF + wdst) = wlr;                               \
+    }
+
+    f32x4 acc[NT][MT], accl[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) { acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int fr = lane & 15, fq = lane >> 4;
+    int woff[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) woff[a] = swz(wc * TC + a * 16 + fr, fq);
+
+    EV_S_GLOAD_X(0)
+    EV_S_GLOAD_W(0, 0)
+    EV_S_SSTORE_X(0)
+    EV_S_SSTORE_W(0)
+    __syncthreads();
+    int kc = 0, tap = 0, wsel = 0;
+    for (int s = 0; s < steps; ++s) {
+        int t1 = tap + 1, k1 = kc;
+        if (t1 == taps) { t1 = 0; k1 = kc + 1; }
+        const bool has_next = s + 1 < steps;
+        const bool next_x = has_next && t1 == 0;
+        if (has_next) EV_S_GLOAD_W(k1, t1)
+        if (next_x) EV_S_GLOAD_X(k1)
+        {
+            const int row0 = wt * TT + fr + tap * p.dil;
+            const int xo = (kc & 1) * XBUF + row0 * 64 + ((fq ^ ((row0 >> 1) & 3)) << 4);
+            uint4 xh[MT], xl[MT], wh[NT], wl[NT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                xh[b] = *reinterpret_cast<const uint4*>(Xh + xo + b * 16 * 64);
+                xl[b] = *reinterpret_cast<const uint4*>(Xl + xo + b * 16 * 64);
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                wh[a] = *reinterpret_cast<const uint4*>(Wh + wsel * WBUF + woff[a]);
+                wl[a] = *reinterpret_cast<const uint4*>(Wl + wsel * WBUF + woff[a]);
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wh[a]), *reinterpret_cast<half8*>(&xh[b]), acc[a][b], 0, 0, 0);
+                    accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wh[a]), *reinterpret_cast<half8*>(&xl[b]), accl[a][b], 0, 0, 0);
+                    accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wl[a]), *reinterpret_cast<half8*>(&xh[b]), accl[a][b], 0, 0, 0);
+                }
+        }
+        if (has_next) EV_S_SSTORE_W(wsel ^ 1)
+        if (next_x) EV_S_SSTORE_X(k1 & 1)
+        __syncthreads();
+        wsel ^= 1;
+        tap = t1;
+        kc = k1;
+    }
+#undef EV_S_GLOAD_X
+#undef EV_S_SPLIT_STORE
+#undef EV_S_SSTORE_X
+#undef EV_S_GLOAD_W
+#undef EV_S_SSTORE_W
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] += accl[a][b] * (1.0f / 2048.0f);
+    gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+}
+
+static void launch_split(const ConvGemmParams& p, hipStream_t s) {
+    constexpr int BM = 128, BN = 64;
+    const size_t lds = 4 * (size_t)(BM + MAX_SPAN) * 64 + 4 * (size_t)BN * 64;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    const int grid = (p.M / BM) * (p.N / BN);
+    hipLaunchKernelGGL((conv_gemm_split_kernel<BM, BN>), dim3(grid), dim3(256), lds, s, p);
+}
+
+// =====================================================================================================================
 // Fused ResBlock pair, C = 32 (HiFi-GAN stage 3: 256 samples x 32 channels per mel frame, the HBM-bound end of the vocoder:
 // layer-wise each conv moves 64 B in + 64 B out per sample for 2*32*32*k FLOP).  One persistent block per CU:
 //   * W1 and W2 (k taps x 32 x 32 fp16 each, <= 22.5 KB) are loaded into LDS once per block and stay there; every wave
@@ -640,6 +804,7 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {
     // preconditions are checked by the engine (ev_engine.cpp: check_gemm)
     if (p.dtype == DT_F16) launch_dt<_Float16>(p, s);
+    else if (p.dtype == DT_F32S) launch_split(p, s);
     else launch_dt<float>(p, s);
 }
 

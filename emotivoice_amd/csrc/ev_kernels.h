@@ -8,7 +8,7 @@
 namespace ev {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LRELU = 3, ACT_TANH = 4 };
-enum DType { DT_F16 = 0, DT_F32 = 1 };
+enum DType { DT_F16 = 0, DT_F32 = 1, DT_F32S = 2 };   // F32S: fp32 activations, fp16 hi/lo split weights (ConvGemmParams::W / W_lo)
 
 // out[m, n] = post( scale * ( act( sum_{tap,k} pro(A[m + (tap-center)*dil, k]) * W[n][tap][k] + bias[n] )
 //                              + seq_bias[row_seq[m]][n] + res[m, n] ) + acc32[m, n] )
@@ -19,7 +19,8 @@ enum DType { DT_F16 = 0, DT_F32 = 1 };
 struct ConvGemmParams {
     int dtype;              // DT_F16: A/W fp16, MFMA f32_16x16x32_f16; DT_F32: A/W fp32, MFMA f32_16x16x4_f32 (exact fp32)
     const void* A; int lda; // activations, row pitch in elements; rows [-64, M+64) must be readable
-    const void* W;          // [N][taps][K], K contiguous
+    const void* W;          // [N][taps][K], K contiguous (DT_F32S: fp16 "hi" part)
+    const void* W_lo;       // DT_F32S only: fp16((w - hi) * 2048), same layout
     const float* bias;      // [N] or null
     int M, N, K, taps, dil, center;
     const uint8_t* row_valid; int valid_shift;   // null -> all rows valid

@@ -14,7 +14,8 @@ class EVError(RuntimeError):
     pass
 
 
-def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages: bool = False) -> _ffi.ev_config:
+def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages: bool = False,
+                   token_rate: str = "split") -> _ffi.ev_config:
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
     for f in ("n_vocab", "n_speaker", "n_mels", "hidden", "heads", "enc_layers", "dec_layers", "ffn_kernel", "bert_dim",
@@ -32,6 +33,7 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages
     cfg.sample_rate = int(shapes.sr)
     cfg.decoder_precision = {"f16": _ffi.EV_PREC_F16, "f32": _ffi.EV_PREC_F32}[decoder_precision]
     cfg.keep_stages = 1 if keep_stages else 0
+    cfg.token_rate_split = {"split": 1, "f32": 0}[token_rate]
     return cfg
 
 
@@ -39,11 +41,11 @@ class EVEngine:
     """One handle = one GPU + one stream + one workspace (include/evhip.h).  Not thread-safe."""
 
     def __init__(self, shapes: Optional[EVShapes] = None, device_id: int = 0, decoder_precision: str = "f16",
-                 keep_stages: bool = False):
+                 keep_stages: bool = False, token_rate: str = "split"):
         self.shapes = shapes or EVShapes()
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
-        cfg = make_ev_config(self.shapes, decoder_precision, keep_stages)
+        cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate)
         if self._lib.ev_create(device_id, C.byref(cfg), C.byref(self._h)) != 0:
             raise EVError(self._lib.ev_last_error(None).decode())
         self.device_id = device_id

@@ -118,6 +118,15 @@ class _Blob:
         self.add(name + "32", arr, DT_F32)
         self.add(name + "16", arr, DT_F16)
 
+    def split(self, name: str, arr: np.ndarray):
+        """fp32 weight as an fp16 hi/lo pair for the split-precision GEMM (ev_gemm.hip: conv_gemm_split_kernel):
+        w = hi + 2^-11 * lo with hi = fp16(w), lo = fp16((w - hi) * 2^11)."""
+        w = np.ascontiguousarray(arr, np.float32)
+        hi = w.astype(np.float16)
+        lo = ((w - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        self.add(name + "32h", hi, DT_F16)
+        self.add(name + "32l", lo, DT_F16)
+
     def finish(self) -> Tuple[bytes, dict]:
         n = len(self.items)
         off = 16 + n * _ENTRY.size
@@ -168,6 +177,11 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
             wq = [f32(f"{p}.self_attn.linear_{n}.weight") for n in "qkv"]
             bq = [f32(f"{p}.self_attn.linear_{n}.bias") for n in "qkv"]
             b.both(f"{short}.{i}.qkv.w", np.concatenate(wq, 0)[:, None, :])
+            if short == "enc":       # token-rate stack: also as hi/lo split for the split-precision fp32 GEMM
+                b.split(f"{short}.{i}.qkv.w", np.concatenate(wq, 0)[:, None, :])
+                b.split(f"{short}.{i}.out.w", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
+                b.split(f"{short}.{i}.ffn1.w", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))
+                b.split(f"{short}.{i}.ffn2.w", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
             b.add(f"{short}.{i}.qkv.b", np.concatenate(bq, 0), DT_F32)
             b.both(f"{short}.{i}.out.w", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
             b.add(f"{short}.{i}.out.b", f32(f"{p}.self_attn.linear_out.bias"), DT_F32)
@@ -183,12 +197,14 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
 
     wp = f32("am.embed_projection1.weight")              # [H, H + H + 2*bert], column order x|spk|style|content
     b.add("proj.w32", wp[:, None, :H], DT_F32)
+    b.split("proj.w", wp[:, None, :H])
     b.add("proj.wcond", wp[:, H:], DT_F32)
     b.add("proj.b", f32("am.embed_projection1.bias"), DT_F32)
     for short, pre, nl in (("dur", "am.duration_predictor", s.dur_layers), ("pitch", "am.pitch_predictor", s.pitch_layers),
                            ("energy", "am.energy_predictor", s.energy_layers)):
         for i in range(nl):
             b.add(f"{short}.{i}.conv.w32", _conv_to_gemm(f32(f"{pre}.conv.{i}.0.weight")), DT_F32)
+            b.split(f"{short}.{i}.conv.w", _conv_to_gemm(f32(f"{pre}.conv.{i}.0.weight")))
             b.add(f"{short}.{i}.conv.b", f32(f"{pre}.conv.{i}.0.bias"), DT_F32)
             b.add(f"{short}.{i}.ln.g", f32(f"{pre}.conv.{i}.2.weight"), DT_F32)
             b.add(f"{short}.{i}.ln.b", f32(f"{pre}.conv.{i}.2.bias"), DT_F32)

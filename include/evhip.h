@@ -64,7 +64,9 @@ typedef struct ev_config {
     /* engine options (not in the reference) */
     int32_t decoder_precision;  /* EV_PREC_F16 (default) or EV_PREC_F32 (strict parity mode) */
     int32_t keep_stages;        /* !=0: keep every Appendix-C stage tap retrievable by ev_get_stage */
-    int32_t reserved[8];
+    int32_t token_rate_split;   /* 1 (default): fp32 token-rate GEMMs as 3 fp16 MFMAs on hi/lo splits (fp32-level accuracy,
+                                   ~4x faster); 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+    int32_t reserved[7];
 } ev_config;
 
 enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1 };

@@ -19,9 +19,11 @@ extern "C" {
  *                               + seq_bias[row_seq[m]][n] + res[m,n] ) + acc32[m,n] ), invalid rows -> 0
  * Field order and types mirror ev::ConvGemmParams exactly. */
 typedef struct ev_conv_gemm_desc {
-    int dtype;                 /* 0: fp16 operands (MFMA 16x16x32 f16), 1: fp32 operands (MFMA 16x16x4 f32) */
+    int dtype;                 /* 0: fp16 operands (MFMA 16x16x32 f16), 1: fp32 operands (MFMA 16x16x4 f32),
+                                  2: fp32 activations x fp16 hi/lo split weights, 3 fp16 MFMAs per product (fp32-level accuracy) */
     const void* A; int lda;
     const void* W;
+    const void* W_lo;          /* dtype 2 only */
     const float* bias;
     int M, N, K, taps, dil, center;
     const uint8_t* row_valid; int valid_shift;

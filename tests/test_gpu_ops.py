@@ -290,3 +290,38 @@ def test_fused_resblock_pair_c32(lib, k, dil):
     assert _rel(out32.cpu(), ref) < 1e-4, (k, dil)
     assert _rel(out16.float().cpu(), ref_post) < 6e-4
     assert float(out32[~vrow].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,N,taps", [(256, 384, 384, 1), (512, 384, 1536, 3), (256, 1536, 384, 3), (256, 384, 1152, 1)])
+def test_split_precision_gemm_matches_fp32(lib, M, K, N, taps):
+    """fp32 activations x (hi, lo) fp16 weight split, 3 fp16 MFMAs per product: fp32-level agreement with an fp64 reference
+    (the token-rate path must keep durations bit-exact, so this is held to the same 1e-5 bound as the exact fp32 MFMA kernel,
+    and the error is reported next to the exact kernel's)."""
+    from emotivoice_amd import _ffi
+    torch.manual_seed(M + K + N)
+    full, x = _padded(M, K, torch.float32)
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    w = torch.randn(N, K, taps, device="cuda") / math.sqrt(K * taps)
+    bias = torch.randn(N, device="cuda")
+    wg = w.permute(0, 2, 1).contiguous()
+    hi = wg.half()
+    lo = ((wg - hi.float()) * 2048.0).half()
+    ref = F.conv1d(x.double().cpu().t().unsqueeze(0), w.double().cpu(), bias.double().cpu(), padding=(taps - 1) // 2).squeeze(0).t()
+    errs = {}
+    for dtype in (2, 1):
+        d = _ffi.ev_conv_gemm_desc()
+        d.dtype, d.A, d.lda = dtype, x.data_ptr(), K
+        if dtype == 2:
+            d.W, d.W_lo = hi.data_ptr(), lo.data_ptr()
+        else:
+            d.W = wg.data_ptr()
+        d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), M, N, K, taps, 1, (taps - 1) // 2, 1.0
+        out = torch.full((M, N), 7.0, device="cuda")
+        d.out32, d.ldo = out.data_ptr(), N
+        torch.cuda.synchronize()
+        assert lib.ev_op_conv_gemm(C.byref(d), None) == 0
+        torch.cuda.synchronize()
+        errs[dtype] = _rel(out.cpu().double(), ref)
+    assert errs[2] < 1e-5 and errs[1] < 1e-5, errs
+    assert errs[2] < 3e-6, errs          # within a small factor of fp32 rounding
