@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int c = tid + i * 256, r = c >> 2, part = c & 3;
-        xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + r) * a_pitch + part * 16;
+        // the slab buffer always has BM + 64 rows (exact chunk counts, no predicates), but rows beyond the conv's real span
+        // re-read the last needed row (a cache hit) instead of pulling 62 unneeded rows per tile from HBM for k = 3
+        const int rs = min(r, BM + (p.taps - 1) * p.dil - 1);
+        xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + rs) * a_pitch + part * 16;
         xdst[i] = swz(r, part);
     }
     const char* wsrc[WCH]; int wdst[WCH];
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int c = tid + i * 256, r = c >> 2, part = c & 3;
-        xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + r) * a_pitch + part * 32;
+        const int rs = min(r, BM + (p.taps - 1) * p.dil - 1);
+        xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + rs) * a_pitch + part * 32;
         xdst[i] = swz(r, part);
     }
     const int wr_ = tid >> 2, wp_ = tid & 3;
