@@ -12,7 +12,7 @@ for st in $STAGES; do
     parity) timeout 1800 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 900 > gpurun_out/parity.log 2>&1; echo "parity rc=$?";;
     smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?";;
     bench)  timeout 900 python bench.py --steps 5 --warmup 2 --cpu-utts 4 > gpurun_out/bench.log 2>&1; echo "bench rc=$?";;
-    gen)    timeout 900 python -m pytest tests/test_gpu_generator.py -m gpu -q --timeout 600 > gpurun_out/gen.log 2>&1; echo "gen rc=$?";;
+    gen)    timeout 900 python -m pytest tests/test_gpu_generator.py tests/test_gpu_api.py -m gpu -q --timeout 600 > gpurun_out/gen.log 2>&1; echo "gen rc=$?";;
     pmc)    cd /tmp && export TMPDIR=/tmp
             timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_fetch" -o f -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --cpu-utts 0 > "$GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log" 2>&1
             timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_write" -o w -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --cpu-utts 0 > "$GRAFT_REPO_ROOT/gpurun_out/pmc_write.log" 2>&1
