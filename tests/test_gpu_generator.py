@@ -85,3 +85,26 @@ def test_cli_flow_config1(tmp_path):
     assert n == 2 and sorted(os.listdir(tmp_path / "out")) == ["1.wav", "2.wav"]
     with wave.open(str(tmp_path / "out" / "1.wav")) as w:
         assert w.getframerate() == 16000 and w.getsampwidth() == 2 and w.getnframes() % 256 == 0 and w.getnframes() > 0
+
+
+def test_predictor_tts_surface(tmp_path):
+    """predict.py:164-194 flow through emotivoice_amd.predict.Predictor."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import wave
+    from emotivoice_amd.predict import Predictor
+    from emotivoice_amd.synthetic import synth_state_dict
+    toks = ["_", "<sos/eos>"] + ["p%d" % i for i in range(500)]
+    (tmp_path / "tokenlist").write_text("\n".join(toks) + "\n")
+    (tmp_path / "speaker2").write_text("\n".join(["8051"] + ["s%d" % i for i in range(2013)]))
+    p = Predictor(str(tmp_path / "tokenlist"), str(tmp_path / "speaker2"), str(tmp_path / "out"))
+    with pytest.raises(RuntimeError):
+        p.tts("<sos/eos> p1 <sos/eos>", "Happy", "hello", "8051")
+    p.setup_models(generator_state_dict=synth_state_dict(0, "parity"))
+    path = p.tts("<sos/eos> p1 p2 p3 p4 p5 <sos/eos>", "Happy", "hello there", "8051")
+    with wave.open(path) as w:
+        assert w.getframerate() == 16000 and w.getnframes() % 256 == 0 and w.getnframes() > 0
+    with pytest.raises(KeyError):
+        p.tts("<sos/eos> nope <sos/eos>", "Happy", "x", "8051")
+    with pytest.raises(KeyError):
+        p.tts("<sos/eos> p1 <sos/eos>", "Happy", "x", "unknown-speaker")
