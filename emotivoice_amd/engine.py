@@ -170,6 +170,25 @@ class EVEngine:
         res = self.vocoder_raw(len(mels), flat.ctypes.data, is16, lens, flags)
         return self.result_to_numpy(res, want_int16)
 
+    # receptive field of the generator in mel frames per side: conv_post 3 samples -> 60-sample ResBlock halos per stage through the
+    # four transposed convs -> 11 frames, + conv_pre 3 = 14 (derivation in DESIGN.md section 4); 16 is used
+    VOCODER_CONTEXT_FRAMES = 16
+
+    def vocoder_chunked(self, mel: np.ndarray, chunk_frames: int = 256, context: Optional[int] = None):
+        """Streaming vocoding of one long mel (n_mels, T): yields the waveform of consecutive chunks of ``chunk_frames`` frames.
+        Every chunk is vocoded with ``context`` extra frames on each side and the centre is kept; because every output sample
+        only depends on +-14 mel frames and the kernels are position-independent, the concatenation is BIT-IDENTICAL to vocoding
+        the whole mel at once (tests/test_gpu_parity.py).  Bounds the vocoder workspace for arbitrarily long utterances and gives
+        first audio after one chunk (ROADMAP "Support longer text", SURVEY.md section 8(f) #2)."""
+        ctx = self.VOCODER_CONTEXT_FRAMES if context is None else context
+        up = self.shapes.upsample_factor
+        T = mel.shape[1]
+        for a in range(0, T, chunk_frames):
+            b = min(T, a + chunk_frames)
+            lo, hi = max(0, a - ctx), min(T, b + ctx)
+            wav = self.vocoder([np.ascontiguousarray(mel[:, lo:hi])])["wav"]
+            yield wav[(a - lo) * up:(b - lo) * up]
+
     def get_stage(self, name: str) -> np.ndarray:
         """Stage tap of the last call (SURVEY.md Appendix C names; needs keep_stages=True): (rows, C) fp32."""
         need = self._lib.ev_get_stage(self._h, name.encode(), None, 0)

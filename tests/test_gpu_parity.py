@@ -309,3 +309,19 @@ def test_long_utterance_extends_positional_table(gpu):
     e = rel_l2(out["mel"], ref["dec_outputs"].numpy())
     _report("long_utt_mel", e)
     assert e < TOL_OUT
+
+
+def test_chunked_vocoding_is_bit_identical(gpu):
+    """Streaming vocoder (EVEngine.vocoder_chunked): chunks with 16 frames of context reproduce whole-utterance vocoding
+    bit for bit; with too little context they do not (the receptive field is 14 frames per side)."""
+    eng = _engine("parity", "f16", keep=False)
+    rng = np.random.default_rng(17)
+    mel = (1.25 * rng.standard_normal((80, 700)) + 0.08).astype(np.float32)
+    full = eng.vocoder([mel])["wav"]
+    for chunk in (256, 100):
+        parts = list(eng.vocoder_chunked(mel, chunk_frames=chunk))
+        assert np.array_equal(np.concatenate(parts), full), chunk
+    short = np.concatenate(list(eng.vocoder_chunked(mel, chunk_frames=256, context=8)))
+    assert short.shape == full.shape and not np.array_equal(short, full)
+    exact14 = np.concatenate(list(eng.vocoder_chunked(mel, chunk_frames=256, context=14)))
+    assert np.array_equal(exact14, full)
