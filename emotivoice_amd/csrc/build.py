@@ -23,12 +23,12 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + ".o")
+def _compile(src, extra=(), tag=""):
+    obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + tag + ".o")
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if _newer(obj, deps):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -52,5 +52,22 @@ def build(force=False):
     return OUT
 
 
+def build_variant(tag, defines):
+    """Tuning variants (e.g. --variant trace EV_TRACE): libevhip_<tag>.so next to the product library, loaded through the
+    EVHIP_LIB environment variable by tools/; never used by the package itself."""
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    extra = ["-D" + d for d in defines]
+    objs = [_compile(src, extra, "_" + tag) for src in SOURCES]
+    out = os.path.join(HERE, "libevhip_%s.so" % tag)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force="--force" in sys.argv))

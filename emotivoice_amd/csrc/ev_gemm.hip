@@ -162,6 +162,144 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4
     }
 }
 
+// ---- fast epilogue of the fp16 kernel.  Same transposed, coalesced stores as gemm_epilogue_lds, but the memory instruction
+// stream is straight-line: per-wave timelines (tools/trace_gemm.py) showed 30-50 % of a tile's lifetime in the generic
+// epilogue, because every iteration loaded its row_valid byte (and residual) inside runtime-flag branches and hipcc had to
+// place s_waitcnt vmcnt(0) in every iteration -- on gfx9 stores share that counter, so each 1-KB store waited for the previous
+// one's round trip.  Here (a) the optional operands are template flags, (b) all row_valid bytes of the wave's tile are
+// requested before the first store (a null row_valid reads a constant 1 through a zero shift), (c) the residual / MRF rows of
+// pass p+1 are requested before the stores of pass p, (d) row masking is a select, not a branch.
+enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8 };
+__device__ const uint8_t g_row_always_valid[4] = {1, 1, 1, 1};
+
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0) {
+    constexpr int TC = NT * 16;
+    constexpr int PITCH = epi_pitch<TC>();
+    constexpr int LPR = TC / 8, RPI = 64 / LPR, IT = 32 / RPI, NP = MT / 2;
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane / LPR, g = lane % LPR;
+    const int co = co0 + g * 8;
+    const int trow = t0 + rr;                                  // row of (pass 0, it 0); + pass * 32 + it * RPI
+
+    // one byte load per 32-row pass (lane l <-> row l & 31), turned into a wave-uniform bit mask by a ballot: no VGPRs held
+    const uint8_t* vptr = p.row_valid ? p.row_valid : g_row_always_valid;
+    const int vshift = p.row_valid ? p.valid_shift : 31;
+    uint8_t vld[NP];
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) vld[pass] = vptr[(t0 + pass * 32 + (lane & 31)) >> vshift];
+    uint4 r16[2][IT];
+    float4 r32[2][IT][2], a32[2][IT][2];
+#define EV_EPI_PREFETCH(PASS)                                                                                              \
+    _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                                                    \
+        const long t_ = trow + (PASS) * 32 + it * RPI;                                                                     \
+        if constexpr (EPI & EPI_RES16)                                                                                     \
+            r16[(PASS) & 1][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.res) + t_ * p.ldres + co); \
+        if constexpr (EPI & EPI_RES32) {                                                                                   \
+            const float* rp_ = reinterpret_cast<const float*>(p.res) + t_ * p.ldres + co;                                  \
+            r32[(PASS) & 1][it][0] = *reinterpret_cast<const float4*>(rp_);                                                \
+            r32[(PASS) & 1][it][1] = *reinterpret_cast<const float4*>(rp_ + 4);                                            \
+        }                                                                                                                  \
+        if constexpr (EPI & EPI_ACC32) {                                                                                   \
+            const float* ap_ = p.acc32 + t_ * p.ldacc + co;                                                                \
+            a32[(PASS) & 1][it][0] = *reinterpret_cast<const float4*>(ap_);                                                \
+            a32[(PASS) & 1][it][1] = *reinterpret_cast<const float4*>(ap_ + 4);                                            \
+        }                                                                                                                  \
+    }
+    EV_EPI_PREFETCH(0)
+    unsigned vmask[NP];
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) vmask[pass] = (unsigned)__builtin_amdgcn_ballot_w64(vld[pass] != 0);
+
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+    const int act = p.act;
+    const float act_slope = p.act_slope, out_scale = p.out_scale;
+    const float post_slope = p.post_lrelu ? p.post_slope : 1.0f;      // slope 1 == identity
+    __half* const o16 = reinterpret_cast<__half*>(p.out16);
+    float* const o32a = p.out32_before_post ? p.out32 : nullptr;
+    float* const o32b = p.out32_before_post ? nullptr : p.out32;
+
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+                *reinterpret_cast<f32x4*>(wave_lds + (bb * 16 + fr) * PITCH + (a * 16 + 4 * fq) * 4) = acc[a][pass * 2 + bb];
+        __builtin_amdgcn_wave_barrier();
+        if (pass + 1 < NP) { EV_EPI_PREFETCH(pass + 1) }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int lr = it * RPI + rr;
+            const long t = trow + pass * 32 + it * RPI;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+            if (act == ACT_LRELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * act_slope;
+            } else if (act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (act == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+            } else if (act == ACT_TANH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            }
+            if constexpr (EPI & EPI_RES16) {
+                const __half2* h = reinterpret_cast<const __half2*>(&r16[pass & 1][it]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); v[2 * e] += f.x; v[2 * e + 1] += f.y; }
+            }
+            if constexpr (EPI & EPI_RES32) {
+                const float4 r0 = r32[pass & 1][it][0], r1 = r32[pass & 1][it][1];
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= out_scale;
+            if constexpr (EPI & EPI_ACC32) {
+                const float4 r0 = a32[pass & 1][it][0], r1 = a32[pass & 1][it][1];
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+            const bool valid = (vmask[pass] >> lr) & 1u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = valid ? v[e] : 0.f;
+            if (o32a) {
+                float* op = o32a + t * p.ldo + co;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * post_slope;
+            if (o32b) {
+                float* op = o32b + t * p.ldo + co;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (o16) {
+                uint4 o;
+                __half2* h = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<uint4*>(o16 + t * p.ldo + co) = o;
+            }
+        }
+    }
+#undef EV_EPI_PREFETCH
+}
+
 // ---- main kernel.  LDS: 64-byte pitch with an XOR swizzle (16-B part ^= (row >> 1) & 3): conflict-free ds_read_b128 for
 // the 16-row fragment reads at ANY tap offset and conflict-free ds_write_b128 staging (bank model of MI355X_MICROARCH.md
 // section LDS; the first version's 80-B padded pitch measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50).
@@ -172,8 +310,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4
 // hipcc spill the prefetch registers to scratch inside the loop).
 __device__ __forceinline__ int swz(int row, int part) { return row * 64 + ((part ^ ((row >> 1) & 3)) << 4); }
 
-template <typename TIn, int BM, int BN, int WT, int WC>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
+// Tuning instrumentation (-DEV_TRACE, tools/trace_gemm.py; never part of the product build): every wave stamps s_memtime
+// around each barrier into LDS, sampled blocks dump their stamps + HW_ID at the end.
+#ifdef EV_TRACE
+static constexpr int TRACE_N = 192;
+static unsigned* g_trace_ptr = nullptr;
+extern "C" void ev_trace_set(void* p) { g_trace_ptr = reinterpret_cast<unsigned*>(p); }
+#define EV_TRACE_ARG , unsigned* trace_out
+#define EV_STAMP()                                                                      \
+    {                                                                                   \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();                     \
+        if (lane == 0 && tr_i < TRACE_N) tr_lds[wave * TRACE_N + tr_i] = t_;            \
+        ++tr_i;                                                                         \
+    }
+#else
+#define EV_TRACE_ARG
+#define EV_STAMP()
+#endif
+
+template <typename TIn, int BM, int BN, int WT, int WC, int EPI>
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & EPI_ACC32)) ? 2 : 3) void conv_gemm_kernel(const ConvGemmParams p EV_TRACE_ARG) {
     constexpr int ES = sizeof(TIn);
     constexpr int TT = BM / WT, TC = BN / WC, MT = TT / 16, NT = TC / 16;
     constexpr int SLAB = BM + MAX_SPAN;              // rows staged per K-chunk (>= BM + (taps-1)*dil, multiple of 64)
@@ -190,6 +346,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     const int wt = wave / WC, wc = wave % WC;
     char* Xs = smem;
     char* Ws = smem + 2 * XBUF;
+#ifdef EV_TRACE
+    constexpr int EPI_ = 4 * 32 * ((BN / WC) * 4 + 16), PIPE_ = 2 * XBUF + 2 * WBUF;
+    unsigned* tr_lds = reinterpret_cast<unsigned*>(smem + (EPI_ > PIPE_ ? EPI_ : PIPE_));
+    int tr_i = 0;
+    EV_STAMP()
+#endif
 
     // XCD-aware block remap (bijective): consecutive logical tiles -> same XCD (shared L2 for the A rows)
     const int nN = p.N / BN;
@@ -293,7 +455,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         const int k1 = (taps > 1) ? 0 : (nkc > 1 ? 1 : 0), t1 = (taps > 1) ? 1 : 0;
         EV_GLOAD_W(wB, k1, t1)
     }
+    EV_STAMP()
     __syncthreads();
+    EV_STAMP()
 
     int wsel = 0;                        // LDS weight buffer holding the current step's tile
     int kc = 0, tap = 0;
@@ -318,7 +482,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         } else {                                                                           \
             ++tap;                                                                         \
         }                                                                                  \
+        EV_STAMP()                                                                         \
         __syncthreads();                                                                   \
+        EV_STAMP()                                                                         \
         wsel ^= 1;                                                                         \
     }
     int s = 0;
@@ -335,18 +501,54 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 #undef EV_SSTORE_W
 
     // all waves passed the barrier that ended the last step: the staging buffers are free for the transpose
-    gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+    if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+    else gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+#ifdef EV_TRACE
+    EV_STAMP()
+    if (trace_out && bid % 61 == 0 && bid / 61 < 128) {
+        unsigned* o = trace_out + (size_t)((bid / 61) * 4 + wave) * (TRACE_N + 8);
+        for (int i = lane; i < TRACE_N; i += 64) o[8 + i] = tr_lds[wave * TRACE_N + i];
+        if (lane == 0) {
+            o[0] = 0xE7ACE000u + wave; o[1] = bid; o[2] = tr_i;
+            o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+            o[5] = blockIdx.x;
+        }
+    }
+#endif
 }
 
-template <typename TIn, int BM, int BN, int WT, int WC>
-static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
-    const int span = (p.taps - 1) * p.dil;
+template <typename TIn, int BM, int BN, int WT, int WC, int EPI>
+static void launch_epi(const ConvGemmParams& p, hipStream_t s) {
     const int grid = (p.M / BM) * (p.N / BN);
-    (void)span;
     size_t lds = 2 * (size_t)(BM + MAX_SPAN) * 64 + 2 * (size_t)BN * 64;
     const size_t epi = 4 * (size_t)(32 * ((BN / WC) * 4 + 16));
     if (epi > lds) lds = epi;
-    hipLaunchKernelGGL((conv_gemm_kernel<TIn, BM, BN, WT, WC>), dim3(grid), dim3(256), lds, s, p);
+#ifdef EV_TRACE
+    lds += 4 * TRACE_N * sizeof(unsigned);
+    hipLaunchKernelGGL((conv_gemm_kernel<TIn, BM, BN, WT, WC, EPI>), dim3(grid), dim3(256), lds, s, p, g_trace_ptr);
+#else
+    hipLaunchKernelGGL((conv_gemm_kernel<TIn, BM, BN, WT, WC, EPI>), dim3(grid), dim3(256), lds, s, p);
+#endif
+}
+
+// epilogue variant: the fp16 kernel specialises the combinations the frame-rate path uses (plain / fp16 residual / fp16
+// residual + MRF accumulate / fp32 residual); anything else (per-utterance bias, the fp32 kernel) takes the generic one
+template <typename TIn, int BM, int BN, int WT, int WC>
+static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
+    if constexpr (sizeof(TIn) == 2) {
+        static const bool force_generic = getenv("EV_EPI_GENERIC") != nullptr;     // A/B switch for tools/bench_gemm.py
+        const int e = p.seq_bias || force_generic ? EPI_GENERIC
+                                  : (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0);
+        switch (e) {
+            case 0: return launch_epi<TIn, BM, BN, WT, WC, 0>(p, s);
+            case EPI_RES16: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES16>(p, s);
+            case EPI_RES16 | EPI_ACC32: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES16 | EPI_ACC32>(p, s);
+            case EPI_RES32: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES32>(p, s);
+            default: break;
+        }
+    }
+    launch_epi<TIn, BM, BN, WT, WC, EPI_GENERIC>(p, s);
 }
 
 template <typename TIn>
