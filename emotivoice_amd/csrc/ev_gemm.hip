@@ -170,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4
 // requested before the first store (a null row_valid reads a constant 1 through a zero shift), (c) the residual / MRF rows of
 // pass p+1 are requested before the stores of pass p, (d) row masking is a select, not a branch.
 enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8 };
-__device__ const uint8_t g_row_always_valid[4] = {1, 1, 1, 1};
+__device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0) {
@@ -746,12 +746,16 @@ static void launch_split(const ConvGemmParams& p, hipStream_t s) {
 //   * conv1's bias + leaky-relu + sequence-edge masking happen in registers, xt goes to LDS as fp16, conv2 reads it with
 //     dilation 1, and the residual / MRF epilogue is the same LDS-transposed coalesced epilogue as the GEMM kernel.
 // HBM traffic per pair: read x once (+ the residual re-read, an L2 hit), write once -- vs 5 tensor passes layer-wise.
-template <int K>
-__global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPairParams p) {
-    // 8 waves x 32 rows: two waves per SIMD hide each other's LDS / global latency (one 4-wave block per CU measured 7 us per
-    // tile, dominated by exposed residual loads in the epilogue); the residual and MRF-accumulate rows of a tile are
-    // requested BEFORE conv2 so that they land during its MFMAs.
-    constexpr int C = 32, H2 = (K - 1) / 2, BMO = 256 - 2 * H2, NW = 8;
+__device__ char g_store_trash[64 * 64];     // masked lanes of the fused kernel's stores land here (no exec-masked branch)
+
+template <int K, bool HAS_ACC>
+__global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPairParams p) {
+    // 8 waves x 32 rows, one persistent block per CU.  The memory instruction stream of the tile loop is straight-line: the
+    // first version loaded row_valid bytes / MRF rows inside runtime-flag branches and an exec-masked third slab chunk, and
+    // hipcc answered with s_waitcnt vmcnt(0) right after the next tile's slab prefetch (no prefetch at all) and between the
+    // stores.  Now per tile, in issue order: [MRF rows of THIS tile] [slab + row-valid byte of the NEXT tile] conv1 -> xt ->
+    // conv2 -> next slab to LDS -> stores; every wait is counted, the stores drain under the next tile's conv1.
+    constexpr int C = 32, H2 = (K - 1) / 2, BMO = 256 - 2 * H2;
     constexpr int XROWS = 384, XTROWS = 272, XCH = XROWS * 4 / 512;
     constexpr int WBYTES = K * C * 64, XBYTES = XROWS * 64, XTBYTES = XTROWS * 64;
     constexpr int EPITCH = C * 4 + 16, EBYTES = 32 * EPITCH;          // per-wave transpose scratch: 32 rows x 32 fp32
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
     char* W2s = smem + WBYTES;
     char* Xa = smem + 2 * WBYTES;            // [2][XROWS][64]
     char* Xt = Xa + 2 * XBYTES;              // [XTROWS][64]
-    char* Es = Xt + XTBYTES;                 // [NW][EBYTES]
+    char* Es = Xt + XTBYTES;                 // [8][EBYTES]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int h1 = H2 * p.dil;
@@ -785,18 +789,37 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
     float b2v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) b2v[q] = e.bias ? e.bias[eco + q] : 0.f;
+    const float out_scale = e.out_scale;
+    const float post_slope = e.post_lrelu ? e.post_slope : 1.0f;
+    __half* const o16 = reinterpret_cast<__half*>(e.out16);
+    float* const o32a = e.out32_before_post ? e.out32 : nullptr;
+    float* const o32b = e.out32_before_post ? nullptr : e.out32;
+    char* const trash = g_store_trash + lane * 64;
 
-    uint4 xr0, xr1, xr2 = make_uint4(0, 0, 0, 0);
+    // row validity of a tile: lane l of wave w looks at global row (tile * BMO - H2 + 32 w + l); a ballot turns the 64 bytes
+    // into a wave-uniform mask.  conv1's xt rows use bits [0, 32), the output rows bits [H2, H2 + 32).
+    const uint8_t* vptr = e.row_valid ? e.row_valid : g_row_always_valid;
+    const int vshift = e.row_valid ? e.valid_shift : 31;
+#define EV_PAIR_VROW(TILE) ((long)(TILE) * BMO - H2 + wave * 32 + lane)
+#define EV_PAIR_VLOAD(TILE, DST)                                                                           \
+    {                                                                                                      \
+        const long g_ = EV_PAIR_VROW(TILE);                                                                \
+        DST = vptr[(g_ < 0 ? 0 : (g_ >= p.M ? (long)p.M - 1 : g_)) >> vshift];                             \
+    }
+#define EV_PAIR_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_PAIR_VROW(TILE) >= 0 && EV_PAIR_VROW(TILE) < p.M)
+
+    uint4 xr0, xr1, xr2;
     const int xd0 = swz(tid >> 2, tid & 3), xd1 = swz((tid + 512) >> 2, tid & 3), xd2 = swz((tid + 1024) >> 2, tid & 3);
     static_assert(XCH == 3, "three 16-B chunks per thread");
+    // rows beyond the slab the convs read (256 + 2 h1 + 2 H2 <= 316) re-read the last needed row: a cache hit, not HBM traffic
 #define EV_PAIR_ROW(G) ((G) < -64 ? -64 : ((G) > (long)p.M + 63 ? (long)p.M + 63 : (G)))
 #define EV_PAIR_GLOAD(TILE)                                                                                \
     {                                                                                                      \
         const long g0_ = (long)(TILE) * BMO - H2 - h1 + (tid >> 2);                                        \
+        const long g2_ = (long)(TILE) * BMO - H2 - h1 + min((tid >> 2) + 256, 255 + 2 * h1 + 2 * H2);      \
         xr0 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_) * x_pitch + (tid & 3) * 16);           \
         xr1 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_ + 128) * x_pitch + (tid & 3) * 16);     \
-        if ((tid >> 2) < 2 * h1 + 2 * H2)                                                                   \
-            xr2 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_ + 256) * x_pitch + (tid & 3) * 16); \
+        xr2 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g2_) * x_pitch + (tid & 3) * 16);           \
     }
 #define EV_PAIR_SSTORE(BUF)                                                                                \
     {                                                                                                      \
@@ -805,15 +828,18 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
         *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd2) = xr2;                                        \
     }
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
+    int tile = blockIdx.x;                    // grid <= ntiles
+    unsigned long long vmask;
+    {
+        uint8_t vb;
         EV_PAIR_GLOAD(tile)
+        EV_PAIR_VLOAD(tile, vb)
         EV_PAIR_SSTORE(0)
+        vmask = EV_PAIR_VMASK(tile, vb);
     }
     __syncthreads();
-    // both convs' weight fragments (2 * k * 2 x 16 B per lane, 176 VGPRs at k = 11) stay in registers for every tile of this
-    // persistent block: re-reading them from LDS per tile cost as much LDS bandwidth as the activation fragments themselves
-    // (k = 11: both sets = 176 VGPRs would spill at 2 waves / SIMD; conv2's set is then re-read from LDS per tile)
+    // conv1's weight fragments (k * 2 x 16 B per lane) stay in registers for every tile of this persistent block, conv2's too
+    // up to k = 7 (k = 11: 176 VGPRs for both sets; conv2's set is then re-read from LDS per tile)
     constexpr bool W2_RESIDENT = (K <= 7);
     uint4 wf1[K][2], wf2[K][2];
 #pragma unroll
@@ -827,11 +853,24 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
     const int wrow0 = wave * 32 + fr;
     char* es = Es + wave * EBYTES;
     for (; tile < ntiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        const bool more = next < ntiles;
-        if (more) EV_PAIR_GLOAD(next)
+        const int next = min(tile + (int)gridDim.x, ntiles - 1);      // clamped: the last prefetch of a block is never used
         const int m0 = tile * BMO;
         const int t_end = min(m0 + BMO, p.M);
+        // ---------------- memory requests of this iteration, oldest first
+        float4 accin[2][2];
+        if constexpr (HAS_ACC) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int t = min(m0 + wave * 32 + it * 16 + er, t_end - 1);
+                const float* ap = e.acc32 + (long)t * e.ldacc + eco;
+                accin[it][0] = *reinterpret_cast<const float4*>(ap);
+                accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
+            }
+        }
+        uint8_t vb_next;
+        EV_PAIR_GLOAD(next)
+        EV_PAIR_VLOAD(next, vb_next)
+        __builtin_amdgcn_sched_barrier(0);    // hipcc otherwise sinks these requests below conv1, next to their use
         f32x4 acc[2][2];
         // ---------------- conv1 (dilation d): 256 rows, global rows m0 - H2 + r1
 #pragma unroll
@@ -859,8 +898,7 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int r1 = wrow0 + b * 16;
-            const long g = (long)m0 - H2 + r1;
-            const bool valid = g >= 0 && g < p.M && (e.row_valid ? e.row_valid[g >> e.valid_shift] != 0 : true);
+            const bool valid = (vmask >> (fr + b * 16)) & 1ull;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 _Float16 hv[4];
@@ -874,26 +912,11 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
                 *reinterpret_cast<uint2*>(Xt + swz(r1, co >> 3) + (co & 7) * 2) = *reinterpret_cast<uint2*>(hv);
             }
         }
-        // request this wave's residual (and MRF accumulate) rows now: they arrive while conv2 runs
+        // residual x[t] straight from the LDS slab (slab row = H2 + h1 + (t - m0)), no second trip to L2 / HBM
         uint4 resv[2];
-        float4 accin[2][2];
-        bool rowok[2], rowvalid[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int t = m0 + wave * 32 + it * 16 + er;
-            rowok[it] = t < t_end;
-            const int tc = rowok[it] ? t : (t_end - 1);
-            rowvalid[it] = e.row_valid ? e.row_valid[tc >> e.valid_shift] != 0 : true;
-            // residual x[t] straight from the LDS slab (slab row = H2 + h1 + (t - m0)), no second trip to L2 / HBM
-            resv[it] = *reinterpret_cast<const uint4*>(Xa + cur * XBYTES + swz(H2 + h1 + (tc - m0), eg));
-            if (e.acc32) {
-                const float* ap = e.acc32 + (long)tc * e.ldacc + eco;
-                accin[it][0] = *reinterpret_cast<const float4*>(ap);
-                accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
-            } else {
-                accin[it][0] = accin[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        for (int it = 0; it < 2; ++it)
+            resv[it] = *reinterpret_cast<const uint4*>(Xa + cur * XBYTES + swz(H2 + h1 + wave * 32 + it * 16 + er, eg));
         __syncthreads();
         // ---------------- conv2 (dilation 1): rows m0 + r2, reads Xt rows r2 + t
         if constexpr (!W2_RESIDENT) {
@@ -919,6 +942,11 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
                                                                        *reinterpret_cast<half8*>(&xf), acc[a][b], 0, 0, 0);
             }
         }
+        // ---------------- the next tile's slab goes to the idle buffer BEFORE this tile's stores are issued, so that its wait
+        // (the oldest requests in flight) never has to drain them
+        __builtin_amdgcn_sched_barrier(0);    // ... and hoists their wait into conv2
+        EV_PAIR_SSTORE(cur ^ 1)
+        const unsigned long long vmask_next = EV_PAIR_VMASK(next, vb_next);
         // ---------------- epilogue: transpose through the wave's scratch, then 16-byte row-contiguous stores
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -931,54 +959,54 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_c32_kernel(const ResPair
         for (int it = 0; it < 2; ++it) {
             const int lr = it * 16 + er;
             const int t = m0 + wave * 32 + lr;
+            const bool rowok = t < t_end;
+            const bool valid = (vmask >> (H2 + lr)) & 1ull;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32 + 16);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (rowvalid[it]) {
-                const __half2* hh = reinterpret_cast<const __half2*>(&resv[it]);
+            const __half2* hh = reinterpret_cast<const __half2*>(&resv[it]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float2 f = __half22float2(hh[q]);
-                    v[2 * q] = (v[2 * q] + b2v[2 * q] + f.x) * e.out_scale;
-                    v[2 * q + 1] = (v[2 * q + 1] + b2v[2 * q + 1] + f.y) * e.out_scale;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const float2 f = __half22float2(hh[q]);
+                v[2 * q] = (v[2 * q] + b2v[2 * q] + f.x) * out_scale;
+                v[2 * q + 1] = (v[2 * q + 1] + b2v[2 * q + 1] + f.y) * out_scale;
+            }
+            if constexpr (HAS_ACC) {
                 v[0] += accin[it][0].x; v[1] += accin[it][0].y; v[2] += accin[it][0].z; v[3] += accin[it][0].w;
                 v[4] += accin[it][1].x; v[5] += accin[it][1].y; v[6] += accin[it][1].z; v[7] += accin[it][1].w;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = 0.f;
             }
-            if (rowok[it]) {
-                if (e.out32 && e.out32_before_post) {
-                    float* op = e.out32 + (long)t * e.ldo + eco;
-                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-                if (e.post_lrelu) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * e.post_slope;
-                }
-                if (e.out32 && !e.out32_before_post) {
-                    float* op = e.out32 + (long)t * e.ldo + eco;
-                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-                if (e.out16) {
-                    uint4 o;
-                    __half2* h = reinterpret_cast<__half2*>(&o);
+            for (int q = 0; q < 8; ++q) v[q] = valid ? v[q] : 0.f;
+            if (o32a) {
+                float* op = rowok ? o32a + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) h[q] = __floats2half2_rn(v[2 * q], v[2 * q + 1]);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(e.out16) + (long)t * e.ldo + eco) = o;
-                }
+            for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * post_slope;
+            if (o32b) {
+                float* op = rowok ? o32b + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (o16) {
+                uint4 o;
+                __half2* h = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = __floats2half2_rn(v[2 * q], v[2 * q + 1]);
+                *reinterpret_cast<uint4*>(rowok ? reinterpret_cast<char*>(o16 + (long)t * e.ldo + eco) : trash) = o;
             }
         }
-        if (more) EV_PAIR_SSTORE(cur ^ 1)
+        vmask = vmask_next;
         __syncthreads();
         cur ^= 1;
     }
 #undef EV_PAIR_GLOAD
 #undef EV_PAIR_SSTORE
 #undef EV_PAIR_ROW
+#undef EV_PAIR_VROW
+#undef EV_PAIR_VLOAD
+#undef EV_PAIR_VMASK
 }
 
 static size_t pair_lds_bytes(int k) { return 2 * (size_t)k * 32 * 64 + 2 * 384 * 64 + 272 * 64 + 8 * 32 * (32 * 4 + 16); }
@@ -991,20 +1019,26 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
         // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
-        (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(3));
-        (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(7));
-        (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(11));
+#define EV_PAIR_ATTR(KK)                                                                                              \
+    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK)); \
+    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK));
+        EV_PAIR_ATTR(3) EV_PAIR_ATTR(7) EV_PAIR_ATTR(11)
+#undef EV_PAIR_ATTR
     }
     const int h2 = (p.k - 1) / 2, bmo = 256 - 2 * h2;
     const int ntiles = (p.M + bmo - 1) / bmo;
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     const size_t lds = pair_lds_bytes(p.k);
+#define EV_PAIR_LAUNCH(KK)                                                                                          \
+    case KK:                                                                                                        \
+        if (p.epi.acc32) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, true>), dim3(grid), dim3(512), lds, s, p); \
+        else hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, false>), dim3(grid), dim3(512), lds, s, p);           \
+        break;
     switch (p.k) {
-        case 3: hipLaunchKernelGGL((resblock_pair_c32_kernel<3>), dim3(grid), dim3(512), lds, s, p); break;
-        case 7: hipLaunchKernelGGL((resblock_pair_c32_kernel<7>), dim3(grid), dim3(512), lds, s, p); break;
-        case 11: hipLaunchKernelGGL((resblock_pair_c32_kernel<11>), dim3(grid), dim3(512), lds, s, p); break;
+        EV_PAIR_LAUNCH(3) EV_PAIR_LAUNCH(7) EV_PAIR_LAUNCH(11)
         default: break;
     }
+#undef EV_PAIR_LAUNCH
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {
