@@ -1046,6 +1046,7 @@ int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* stream) {
     ResPairParams p;
     memcpy(&p, d, sizeof p);
     if (p.k != 3 && p.k != 7 && p.k != 11) return -2;
+    if (p.epi.post_lrelu && !(p.epi.post_slope >= 0.f && p.epi.post_slope <= 1.f)) return -2;   // max(v, s v) form of leaky-relu
     launch_resblock_pair_c32(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -28,20 +28,41 @@ namespace ev {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 static constexpr int MAX_SPAN = 64;
 
+// v_max without the canonicalising "v_max x, x" hipcc puts in front of every IEEE-mode fmax whose operand is not provably
+// quiet (one extra VALU per element in VALU-bound epilogues); the operands here are finite activations.
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max_f16_raw(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint4 lrelu_h8(uint4 v, float slope) {
     half8 h = *reinterpret_cast<half8*>(&v);
     const _Float16 s = (_Float16)slope;
-    h = __builtin_elementwise_max(h, h * s);   // slope in (0,1): max(x, slope*x) == leaky_relu(x)
-    return *reinterpret_cast<uint4*>(&h);
+    h = h * s;                                  // slope in (0,1): max(x, slope*x) == leaky_relu(x)
+    const uint4 t = *reinterpret_cast<uint4*>(&h);
+    return make_uint4(pk_max_f16_raw(v.x, t.x), pk_max_f16_raw(v.y, t.y), pk_max_f16_raw(v.z, t.z), pk_max_f16_raw(v.w, t.w));
 }
 __device__ __forceinline__ uint4 lrelu_f4(uint4 v, float slope) {
     float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = fmaxf(f[i], f[i] * slope);
     return v;
+}
+
+// leaky-relu with slope in [0, 1] on a packed pair: max(v, slope * v) = v_pk_mul_f32 + 2 v_max_f32
+__device__ __forceinline__ f32x2 lrelu2(f32x2 v, f32x2 slope2) {
+    const f32x2 t = v * slope2;
+    return f32x2{max_raw(v[0], t[0]), max_raw(v[1], t[1])};
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -162,6 +183,30 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4
     }
 }
 
+// Tuning instrumentation (-DEV_TRACE, tools/trace_gemm.py; never part of the product build): every wave stamps s_memtime
+// around each barrier into LDS, sampled blocks dump their stamps + HW_ID at the end.
+#ifdef EV_TRACE
+static constexpr int TRACE_N = 192;
+static unsigned* g_trace_ptr = nullptr;
+static int g_trace_flags = 0;                     // bit 0: drop the output stores (compute + loads only ceiling)
+extern "C" void ev_trace_set(void* p) { g_trace_ptr = reinterpret_cast<unsigned*>(p); }
+extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
+#define EV_TRACE_ARG , unsigned* trace_out, int trace_flags
+#define EV_TRACE_EPI_PARAMS , unsigned* tr_lds, int& tr_i, int wave
+#define EV_TRACE_EPI_ARGS , tr_lds, tr_i, wave
+#define EV_STAMP()                                                                      \
+    {                                                                                   \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();                     \
+        if (lane == 0 && tr_i < TRACE_N) tr_lds[wave * TRACE_N + tr_i] = t_;            \
+        ++tr_i;                                                                         \
+    }
+#else
+#define EV_TRACE_ARG
+#define EV_TRACE_EPI_PARAMS
+#define EV_TRACE_EPI_ARGS
+#define EV_STAMP()
+#endif
+
 // ---- fast epilogue of the fp16 kernel.  Same transposed, coalesced stores as gemm_epilogue_lds, but the memory instruction
 // stream is straight-line: per-wave timelines (tools/trace_gemm.py) showed 30-50 % of a tile's lifetime in the generic
 // epilogue, because every iteration loaded its row_valid byte (and residual) inside runtime-flag branches and hipcc had to
@@ -169,11 +214,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4
 // one's round trip.  Here (a) the optional operands are template flags, (b) all row_valid bytes of the wave's tile are
 // requested before the first store (a null row_valid reads a constant 1 through a zero shift), (c) the residual / MRF rows of
 // pass p+1 are requested before the stores of pass p, (d) row masking is a select, not a branch.
-enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8 };
+enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16 };   // RARE_ACT: relu / gelu / tanh (runtime switch)
 __device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0) {
+__device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0 EV_TRACE_EPI_PARAMS) {
     constexpr int TC = NT * 16;
     constexpr int PITCH = epi_pitch<TC>();
     constexpr int LPR = TC / 8, RPI = 64 / LPR, IT = 32 / RPI, NP = MT / 2;
@@ -212,19 +257,30 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) vmask[pass] = (unsigned)__builtin_amdgcn_ballot_w64(vld[pass] != 0);
 
-    float bias8[8];
+    // The per-element VALU work bounds this epilogue (timeline: ~100 VALU per 8 outputs took ~800 cycles per iteration with or
+    // without the stores), so everything is kept in packed-fp32 pairs (v_pk_add / v_pk_mul), leaky-relu is max(v, slope * v)
+    // (slope in [0, 1], checked by the launcher), row masking is skipped for fully valid 32-row groups and works on the packed
+    // fp16 words otherwise.
+    f32x2 bias2[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    for (int j = 0; j < 4; ++j) bias2[j] = f32x2{0.f, 0.f};
     if (p.bias) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
-        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        bias2[0] = f32x2{b0.x, b0.y}; bias2[1] = f32x2{b0.z, b0.w}; bias2[2] = f32x2{b1.x, b1.y}; bias2[3] = f32x2{b1.z, b1.w};
     }
     const int act = p.act;
-    const float act_slope = p.act_slope, out_scale = p.out_scale;
-    const float post_slope = p.post_lrelu ? p.post_slope : 1.0f;      // slope 1 == identity
+    const f32x2 act_slope2 = f32x2{p.act_slope, p.act_slope};
+    const f32x2 out_scale2 = f32x2{p.out_scale, p.out_scale};
+    const bool has_post = p.post_lrelu != 0;
+    const f32x2 post_slope2 = f32x2{p.post_slope, p.post_slope};
     __half* const o16 = reinterpret_cast<__half*>(p.out16);
     float* const o32a = p.out32_before_post ? p.out32 : nullptr;
     float* const o32b = p.out32_before_post ? nullptr : p.out32;
+    const long rowoff = (long)trow * p.ldo + co;
+    unsigned lrbit[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) lrbit[it] = 1u << (it * RPI + rr);
+    EV_STAMP()
 
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
@@ -236,65 +292,63 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 *reinterpret_cast<f32x4*>(wave_lds + (bb * 16 + fr) * PITCH + (a * 16 + 4 * fq) * 4) = acc[a][pass * 2 + bb];
         __builtin_amdgcn_wave_barrier();
         if (pass + 1 < NP) { EV_EPI_PREFETCH(pass + 1) }
+        EV_STAMP()
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int lr = it * RPI + rr;
-            const long t = trow + pass * 32 + it * RPI;
+            const long off = rowoff + (long)(pass * 32 + it * RPI) * p.ldo;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32 + 16);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-            if (act == ACT_LRELU) {
+            for (int j = 0; j < 4; ++j) v[j] += bias2[j];
+            if constexpr (EPI & EPI_RARE_ACT) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * act_slope;
-            } else if (act == ACT_RELU) {
+                for (int j = 0; j < 4; ++j) { v[j][0] = apply_act(v[j][0], act, 0.f); v[j][1] = apply_act(v[j][1], act, 0.f); }
+            } else if (act == ACT_LRELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (act == ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
-            } else if (act == ACT_TANH) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+                for (int j = 0; j < 4; ++j) v[j] = lrelu2(v[j], act_slope2);
             }
             if constexpr (EPI & EPI_RES16) {
-                const __half2* h = reinterpret_cast<const __half2*>(&r16[pass & 1][it]);
+                const half2v* h = reinterpret_cast<const half2v*>(&r16[pass & 1][it]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); v[2 * e] += f.x; v[2 * e + 1] += f.y; }
+                for (int j = 0; j < 4; ++j) v[j] += __builtin_convertvector(h[j], f32x2);
             }
             if constexpr (EPI & EPI_RES32) {
                 const float4 r0 = r32[pass & 1][it][0], r1 = r32[pass & 1][it][1];
-                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= out_scale;
+            for (int j = 0; j < 4; ++j) v[j] *= out_scale2;
             if constexpr (EPI & EPI_ACC32) {
                 const float4 r0 = a32[pass & 1][it][0], r1 = a32[pass & 1][it][1];
-                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
             }
-            const bool valid = (vmask[pass] >> lr) & 1u;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = valid ? v[e] : 0.f;
+            const bool valid = (vmask[pass] & lrbit[it]) != 0u;
             if (o32a) {
-                float* op = o32a + t * p.ldo + co;
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                float* op = o32a + off;
+                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (has_post) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * post_slope;
+                for (int j = 0; j < 4; ++j) v[j] = lrelu2(v[j], post_slope2);
+            }
             if (o32b) {
-                float* op = o32b + t * p.ldo + co;
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                float* op = o32b + off;
+                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (o16) {
                 uint4 o;
-                __half2* h = reinterpret_cast<__half2*>(&o);
+                half2v* h = reinterpret_cast<half2v*>(&o);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<uint4*>(o16 + t * p.ldo + co) = o;
+                for (int j = 0; j < 4; ++j) h[j] = __builtin_convertvector(v[j], half2v);
+                // zero rows outside the utterances: on the packed words (4 selects instead of 8)
+                o.x = valid ? o.x : 0u; o.y = valid ? o.y : 0u; o.z = valid ? o.z : 0u; o.w = valid ? o.w : 0u;
+                *reinterpret_cast<uint4*>(o16 + off) = o;
             }
+            EV_STAMP()
         }
     }
 #undef EV_EPI_PREFETCH
@@ -309,24 +363,6 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 // keeps counted vmcnt waits; register sets rotate by moves (a runtime A/B parity or lambdas taking array references made
 // hipcc spill the prefetch registers to scratch inside the loop).
 __device__ __forceinline__ int swz(int row, int part) { return row * 64 + ((part ^ ((row >> 1) & 3)) << 4); }
-
-// Tuning instrumentation (-DEV_TRACE, tools/trace_gemm.py; never part of the product build): every wave stamps s_memtime
-// around each barrier into LDS, sampled blocks dump their stamps + HW_ID at the end.
-#ifdef EV_TRACE
-static constexpr int TRACE_N = 192;
-static unsigned* g_trace_ptr = nullptr;
-extern "C" void ev_trace_set(void* p) { g_trace_ptr = reinterpret_cast<unsigned*>(p); }
-#define EV_TRACE_ARG , unsigned* trace_out
-#define EV_STAMP()                                                                      \
-    {                                                                                   \
-        const unsigned t_ = (unsigned)__builtin_readcyclecounter();                     \
-        if (lane == 0 && tr_i < TRACE_N) tr_lds[wave * TRACE_N + tr_i] = t_;            \
-        ++tr_i;                                                                         \
-    }
-#else
-#define EV_TRACE_ARG
-#define EV_STAMP()
-#endif
 
 template <typename TIn, int BM, int BN, int WT, int WC, int EPI>
 __global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & EPI_ACC32)) ? 2 : 3) void conv_gemm_kernel(const ConvGemmParams p EV_TRACE_ARG) {
@@ -501,8 +537,14 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & EPI_ACC32)) ? 2
 #undef EV_SSTORE_W
 
     // all waves passed the barrier that ended the last step: the staging buffers are free for the transpose
-    if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
-    else gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+#ifdef EV_TRACE
+    ConvGemmParams pe = p;
+    if (trace_flags & 1) { pe.out16 = nullptr; pe.out32 = nullptr; }
+#else
+    const ConvGemmParams& pe = p;
+#endif
+    if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(pe, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+    else gemm_epilogue_fast<MT, NT, EPI>(pe, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC EV_TRACE_EPI_ARGS);
 #ifdef EV_TRACE
     EV_STAMP()
     if (trace_out && bid % 61 == 0 && bid / 61 < 128) {
@@ -526,7 +568,7 @@ static void launch_epi(const ConvGemmParams& p, hipStream_t s) {
     if (epi > lds) lds = epi;
 #ifdef EV_TRACE
     lds += 4 * TRACE_N * sizeof(unsigned);
-    hipLaunchKernelGGL((conv_gemm_kernel<TIn, BM, BN, WT, WC, EPI>), dim3(grid), dim3(256), lds, s, p, g_trace_ptr);
+    hipLaunchKernelGGL((conv_gemm_kernel<TIn, BM, BN, WT, WC, EPI>), dim3(grid), dim3(256), lds, s, p, g_trace_ptr, g_trace_flags);
 #else
     hipLaunchKernelGGL((conv_gemm_kernel<TIn, BM, BN, WT, WC, EPI>), dim3(grid), dim3(256), lds, s, p);
 #endif
@@ -538,10 +580,15 @@ template <typename TIn, int BM, int BN, int WT, int WC>
 static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     if constexpr (sizeof(TIn) == 2) {
         static const bool force_generic = getenv("EV_EPI_GENERIC") != nullptr;     // A/B switch for tools/bench_gemm.py
-        const int e = p.seq_bias || force_generic ? EPI_GENERIC
-                                  : (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0);
+        const bool odd_slope = (p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f)) ||
+                               (p.post_lrelu && !(p.post_slope >= 0.f && p.post_slope <= 1.f));     // max(v, s v) form needs s in [0, 1]
+        const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
+        const int e = p.seq_bias || force_generic || odd_slope ? EPI_GENERIC
+                                  : (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0) |
+                                        (rare_act ? EPI_RARE_ACT : 0);
         switch (e) {
             case 0: return launch_epi<TIn, BM, BN, WT, WC, 0>(p, s);
+            case EPI_RARE_ACT: return launch_epi<TIn, BM, BN, WT, WC, EPI_RARE_ACT>(p, s);
             case EPI_RES16: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES16>(p, s);
             case EPI_RES16 | EPI_ACC32: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES16 | EPI_ACC32>(p, s);
             case EPI_RES32: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES32>(p, s);
@@ -755,6 +802,10 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
     // hipcc answered with s_waitcnt vmcnt(0) right after the next tile's slab prefetch (no prefetch at all) and between the
     // stores.  Now per tile, in issue order: [MRF rows of THIS tile] [slab + row-valid byte of the NEXT tile] conv1 -> xt ->
     // conv2 -> next slab to LDS -> stores; every wait is counted, the stores drain under the next tile's conv1.
+    // VALU budget: timelines showed the block VALU-bound (leaky-relu re-applied to every tap's fragment, scalar fp32 epilogue
+    // math, 64-bit clamped addressing ~ 300-450 VALU per wave and tile against 24-88 MFMAs), so leaky-relu(x) is applied ONCE
+    // while staging the slab (the raw residual rows are re-read from L2 at the top of the tile), xt / output math runs on
+    // packed fp32 pairs, masks act on packed fp16 words and only for 32-row groups that contain invalid rows.
     constexpr int C = 32, H2 = (K - 1) / 2, BMO = 256 - 2 * H2;
     constexpr int XROWS = 384, XTROWS = 272, XCH = XROWS * 4 / 512;
     constexpr int WBYTES = K * C * 64, XBYTES = XROWS * 64, XTBYTES = XTROWS * 64;
@@ -768,7 +819,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int h1 = H2 * p.dil;
-    const long x_pitch = (long)p.ldx * 2;
+    const int x_pitch = p.ldx * 2;           // bytes; (long)row * x_pitch is one v_mad_i64_i32
     const char* xg = reinterpret_cast<const char*>(p.x);
     const int ntiles = (p.M + BMO - 1) / BMO;
     const ConvGemmParams& e = p.epi;
@@ -779,18 +830,21 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
         *reinterpret_cast<uint4*>(W1s + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w1) + off);
         *reinterpret_cast<uint4*>(W2s + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w2) + off);
     }
-    float b1v[2][4];
+    f32x2 b1v[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b1v[a][q] = p.b1[a * 16 + 4 * fq + q];
+        for (int q = 0; q < 2; ++q) b1v[a][q] = f32x2{p.b1[a * 16 + 4 * fq + 2 * q], p.b1[a * 16 + 4 * fq + 2 * q + 1]};
     // coalesced-side mapping of the epilogue: 4 lanes per row (8 channels each), 16 rows per wave-instruction
     const int er = lane >> 2, eg = lane & 3, eco = eg * 8;
-    float b2v[8];
+    const unsigned frbit = 1u << fr, erbit = 1u << er;
+    f32x2 b2v[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) b2v[q] = e.bias ? e.bias[eco + q] : 0.f;
-    const float out_scale = e.out_scale;
-    const float post_slope = e.post_lrelu ? e.post_slope : 1.0f;
+    for (int q = 0; q < 4; ++q) b2v[q] = e.bias ? f32x2{e.bias[eco + 2 * q], e.bias[eco + 2 * q + 1]} : f32x2{0.f, 0.f};
+    const f32x2 out_scale2 = f32x2{e.out_scale, e.out_scale};
+    const bool has_post = e.post_lrelu != 0;
+    const f32x2 post_slope2 = f32x2{e.post_slope, e.post_slope};
+    const f32x2 slope01 = f32x2{0.1f, 0.1f};
     __half* const o16 = reinterpret_cast<__half*>(e.out16);
     float* const o32a = e.out32_before_post ? e.out32 : nullptr;
     float* const o32b = e.out32_before_post ? nullptr : e.out32;
@@ -800,32 +854,36 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
     // into a wave-uniform mask.  conv1's xt rows use bits [0, 32), the output rows bits [H2, H2 + 32).
     const uint8_t* vptr = e.row_valid ? e.row_valid : g_row_always_valid;
     const int vshift = e.row_valid ? e.valid_shift : 31;
-#define EV_PAIR_VROW(TILE) ((long)(TILE) * BMO - H2 + wave * 32 + lane)
+#define EV_PAIR_VROW(TILE) ((TILE) * BMO - H2 + wave * 32 + lane)          /* 32-bit: M < 2^31 rows */
 #define EV_PAIR_VLOAD(TILE, DST)                                                                           \
     {                                                                                                      \
-        const long g_ = EV_PAIR_VROW(TILE);                                                                \
-        DST = vptr[(g_ < 0 ? 0 : (g_ >= p.M ? (long)p.M - 1 : g_)) >> vshift];                             \
+        const int g_ = EV_PAIR_VROW(TILE);                                                                 \
+        DST = vptr[min(max(g_, 0), p.M - 1) >> vshift];                                                    \
     }
 #define EV_PAIR_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_PAIR_VROW(TILE) >= 0 && EV_PAIR_VROW(TILE) < p.M)
 
     uint4 xr0, xr1, xr2;
     const int xd0 = swz(tid >> 2, tid & 3), xd1 = swz((tid + 512) >> 2, tid & 3), xd2 = swz((tid + 1024) >> 2, tid & 3);
     static_assert(XCH == 3, "three 16-B chunks per thread");
+    const char* const xgt = xg + (tid & 3) * 16;
+    const int xrow2 = min((tid >> 2) + 256, 255 + 2 * h1 + 2 * H2);
     // rows beyond the slab the convs read (256 + 2 h1 + 2 H2 <= 316) re-read the last needed row: a cache hit, not HBM traffic
-#define EV_PAIR_ROW(G) ((G) < -64 ? -64 : ((G) > (long)p.M + 63 ? (long)p.M + 63 : (G)))
+    // (the first slab row is >= -(H2 + h1) >= -30, inside the 64 slack rows; only the upper end needs a clamp)
+#define EV_PAIR_ROW(G) min((G), p.M + 63)
 #define EV_PAIR_GLOAD(TILE)                                                                                \
     {                                                                                                      \
-        const long g0_ = (long)(TILE) * BMO - H2 - h1 + (tid >> 2);                                        \
-        const long g2_ = (long)(TILE) * BMO - H2 - h1 + min((tid >> 2) + 256, 255 + 2 * h1 + 2 * H2);      \
-        xr0 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_) * x_pitch + (tid & 3) * 16);           \
-        xr1 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g0_ + 128) * x_pitch + (tid & 3) * 16);     \
-        xr2 = *reinterpret_cast<const uint4*>(xg + EV_PAIR_ROW(g2_) * x_pitch + (tid & 3) * 16);           \
+        const int g0_ = (TILE) * BMO - H2 - h1 + (tid >> 2);                                               \
+        const int g2_ = (TILE) * BMO - H2 - h1 + xrow2;                                                    \
+        xr0 = *reinterpret_cast<const uint4*>(xgt + (long)EV_PAIR_ROW(g0_) * x_pitch);                     \
+        xr1 = *reinterpret_cast<const uint4*>(xgt + (long)EV_PAIR_ROW(g0_ + 128) * x_pitch);               \
+        xr2 = *reinterpret_cast<const uint4*>(xgt + (long)EV_PAIR_ROW(g2_) * x_pitch);                     \
     }
+    // leaky_relu(x, .1) of models.py:51 once per element while staging (not once per tap on the fragments)
 #define EV_PAIR_SSTORE(BUF)                                                                                \
     {                                                                                                      \
-        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd0) = xr0;                                        \
-        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd1) = xr1;                                        \
-        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd2) = xr2;                                        \
+        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd0) = lrelu_h8(xr0, 0.1f);                        \
+        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd1) = lrelu_h8(xr1, 0.1f);                        \
+        *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xd2) = lrelu_h8(xr2, 0.1f);                        \
     }
 
     int tile = blockIdx.x;                    // grid <= ntiles
@@ -857,11 +915,13 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
         const int m0 = tile * BMO;
         const int t_end = min(m0 + BMO, p.M);
         // ---------------- memory requests of this iteration, oldest first
+        uint4 resv[2];          // raw residual rows x[t] (the LDS slab holds leaky_relu(x)); an L2 hit: the slab just came through
         float4 accin[2][2];
-        if constexpr (HAS_ACC) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int t = min(m0 + wave * 32 + it * 16 + er, t_end - 1);
+        for (int it = 0; it < 2; ++it) {
+            const int t = min(m0 + wave * 32 + it * 16 + er, t_end - 1);
+            resv[it] = *reinterpret_cast<const uint4*>(xg + (long)t * x_pitch + eg * 16);
+            if constexpr (HAS_ACC) {
                 const float* ap = e.acc32 + (long)t * e.ldacc + eco;
                 accin[it][0] = *reinterpret_cast<const float4*>(ap);
                 accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
@@ -885,8 +945,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
                 const char* xp = Xb + r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    // the slab holds RAW x (the residual is taken from it below); leaky_relu(x, .1) of models.py:51 on the fragment
-                    uint4 xf = lrelu_h8(*reinterpret_cast<const uint4*>(xp + b * 16 * 64), 0.1f);
+                    uint4 xf = *reinterpret_cast<const uint4*>(xp + b * 16 * 64);
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf1[t][a]),
@@ -895,28 +954,23 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
             }
         }
         // bias + leaky-relu + zero outside the utterance (conv2 must see the reference's zero padding) -> Xt (fp16)
+        const unsigned xtmask = (unsigned)vmask;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int r1 = wrow0 + b * 16;
-            const bool valid = (vmask >> (fr + b * 16)) & 1ull;
+            const bool valid = (xtmask & (frbit << (b * 16))) != 0u;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                _Float16 hv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[a][b][q] + b1v[a][q];
-                    v = v > 0.f ? v : v * 0.1f;
-                    hv[q] = valid ? (_Float16)v : (_Float16)0.f;
-                }
+                const f32x2 lo = lrelu2(f32x2{acc[a][b][0], acc[a][b][1]} + b1v[a][0], slope01);
+                const f32x2 hi = lrelu2(f32x2{acc[a][b][2], acc[a][b][3]} + b1v[a][1], slope01);
+                uint2 w;
+                *reinterpret_cast<half2v*>(&w.x) = __builtin_convertvector(lo, half2v);
+                *reinterpret_cast<half2v*>(&w.y) = __builtin_convertvector(hi, half2v);
+                w.x = valid ? w.x : 0u; w.y = valid ? w.y : 0u;
                 const int co = a * 16 + 4 * fq;
-                *reinterpret_cast<uint2*>(Xt + swz(r1, co >> 3) + (co & 7) * 2) = *reinterpret_cast<uint2*>(hv);
+                *reinterpret_cast<uint2*>(Xt + swz(r1, co >> 3) + (co & 7) * 2) = w;
             }
         }
-        // residual x[t] straight from the LDS slab (slab row = H2 + h1 + (t - m0)), no second trip to L2 / HBM
-        uint4 resv[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-            resv[it] = *reinterpret_cast<const uint4*>(Xa + cur * XBYTES + swz(H2 + h1 + wave * 32 + it * 16 + er, eg));
         __syncthreads();
         // ---------------- conv2 (dilation 1): rows m0 + r2, reads Xt rows r2 + t
         if constexpr (!W2_RESIDENT) {
@@ -955,45 +1009,43 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
             for (int a = 0; a < 2; ++a)
                 *reinterpret_cast<f32x4*>(es + (b * 16 + fr) * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][b];
         __builtin_amdgcn_wave_barrier();
+        const unsigned outmask = (unsigned)(vmask >> H2);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int lr = it * 16 + er;
             const int t = m0 + wave * 32 + lr;
             const bool rowok = t < t_end;
-            const bool valid = (vmask >> (H2 + lr)) & 1ull;
+            const bool valid = (outmask & (erbit << (it * 16))) != 0u;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32 + 16);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const __half2* hh = reinterpret_cast<const __half2*>(&resv[it]);
+            f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
+            const half2v* hh = reinterpret_cast<const half2v*>(&resv[it]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float2 f = __half22float2(hh[q]);
-                v[2 * q] = (v[2 * q] + b2v[2 * q] + f.x) * out_scale;
-                v[2 * q + 1] = (v[2 * q + 1] + b2v[2 * q + 1] + f.y) * out_scale;
-            }
+            for (int q = 0; q < 4; ++q) v[q] = (v[q] + b2v[q] + __builtin_convertvector(hh[q], f32x2)) * out_scale2;
             if constexpr (HAS_ACC) {
-                v[0] += accin[it][0].x; v[1] += accin[it][0].y; v[2] += accin[it][0].z; v[3] += accin[it][0].w;
-                v[4] += accin[it][1].x; v[5] += accin[it][1].y; v[6] += accin[it][1].z; v[7] += accin[it][1].w;
+                v[0] += f32x2{accin[it][0].x, accin[it][0].y}; v[1] += f32x2{accin[it][0].z, accin[it][0].w};
+                v[2] += f32x2{accin[it][1].x, accin[it][1].y}; v[3] += f32x2{accin[it][1].z, accin[it][1].w};
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = valid ? v[q] : 0.f;
             if (o32a) {
                 float* op = rowok ? o32a + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (has_post) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * post_slope;
+                for (int q = 0; q < 4; ++q) v[q] = lrelu2(v[q], post_slope2);
+            }
             if (o32b) {
                 float* op = rowok ? o32b + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (o16) {
                 uint4 o;
-                __half2* h = reinterpret_cast<__half2*>(&o);
+                half2v* h = reinterpret_cast<half2v*>(&o);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) h[q] = __floats2half2_rn(v[2 * q], v[2 * q + 1]);
+                for (int q = 0; q < 4; ++q) h[q] = __builtin_convertvector(v[q], half2v);
+                o.x = valid ? o.x : 0u; o.y = valid ? o.y : 0u; o.z = valid ? o.z : 0u; o.w = valid ? o.w : 0u;
                 *reinterpret_cast<uint4*>(rowok ? reinterpret_cast<char*>(o16 + (long)t * e.ldo + eco) : trash) = o;
             }
         }

@@ -41,11 +41,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="s1_k7,s1_k3,s1_k11,s2_k3,s2_k11,s0_k11,s0_k3")
     ap.add_argument("--out", default="gpurun_out/trace")
+    ap.add_argument("--flags", type=int, default=0, help="bit 0: drop the output stores (compute + loads only)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     lib = _ffi.lib()
     lib.ev_trace_set.argtypes = [C.c_void_p]
     lib.ev_trace_set.restype = None
+    lib.ev_trace_flags.argtypes = [C.c_int]
+    lib.ev_trace_flags.restype = None
+    lib.ev_trace_flags(args.flags)
     for name in args.shapes.split(","):
         dtype, M, K, N, taps, dil, res, pro = SHAPES[name]
         tdt = torch.float16 if dtype == 0 else torch.float32
@@ -104,7 +108,7 @@ def report(name, t, shape, us):
     bar0 = dt[:, 1]
     work = dt[:, 2:2 + 2 * steps:2]
     wait = dt[:, 3:3 + 2 * steps:2]
-    epi = dt[:, 2 + 2 * steps] if dt.shape[1] > 2 + 2 * steps else np.zeros(len(ok))
+    epi = dt[:, 2 + 2 * steps:].sum(axis=1) if dt.shape[1] > 2 + 2 * steps else np.zeros(len(ok))
     total = (st[:, min(n, TRACE_N) - 1] - st[:, 0]) & 0xFFFFFFFF
     ideal = steps * mfma_per_step * (16 if es == 2 else 32)
     print("%-12s tile %dx%d steps %3d  %8.1f us kernel | waves traced %d | cycles per wave: total %7.0f  prologue %6.0f (+bar %5.0f)  "
@@ -115,6 +119,8 @@ def report(name, t, shape, us):
     k = min(steps, 3 * taps)
     print("   work[0:%d] " % k + " ".join("%4.0f" % v for v in work[:, :k].mean(axis=0)))
     print("   wait[0:%d] " % k + " ".join("%4.0f" % v for v in wait[:, :k].mean(axis=0)))
+    if dt.shape[1] > 3 + 2 * steps:      # stamps inside the epilogue: setup | per pass: transpose-in, then one per iteration
+        print("   epilogue segments: " + " ".join("%4.0f" % v for v in dt[:, 2 + 2 * steps:].mean(axis=0)))
     # co-residency: group traced waves by (xcc, cu, simd) from HW_ID
     hw = ok[:, 3]
     print("   hw_id sample: " + " ".join("%08x" % v for v in hw[:4]) + "  xcc " + " ".join(str(v & 15) for v in ok[:4, 4]))
