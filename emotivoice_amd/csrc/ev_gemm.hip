@@ -214,7 +214,9 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 // one's round trip.  Here (a) the optional operands are template flags, (b) all row_valid bytes of the wave's tile are
 // requested before the first store (a null row_valid reads a constant 1 through a zero shift), (c) the residual / MRF rows of
 // pass p+1 are requested before the stores of pass p, (d) row masking is a select, not a branch.
-enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16 };   // RARE_ACT: relu / gelu / tanh (runtime switch)
+// RARE_ACT: relu / gelu / tanh (runtime switch).  O16 / O32: exactly one fp16 / one fp32 (after post) output, so that the number
+// of stores per iteration is a compile-time constant and the counted vmcnt waits of the prefetches never drain them.
+enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64 };
 __device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
 template <int MT, int NT, int EPI>
@@ -293,12 +295,16 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
         __builtin_amdgcn_wave_barrier();
         if (pass + 1 < NP) { EV_EPI_PREFETCH(pass + 1) }
         EV_STAMP()
+        f32x4 lv[IT][2];          // all of the pass's transposed rows first: one exposed LDS latency per pass, not per iteration
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int lr = it * RPI + rr;
+            lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32);
+            lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32 + 16);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
             const long off = rowoff + (long)(pass * 32 + it * RPI) * p.ldo;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(wave_lds + lr * PITCH + g * 32 + 16);
+            const f32x4 v0 = lv[it][0], v1 = lv[it][1];
             f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += bias2[j];
@@ -325,7 +331,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
             }
             const bool valid = (vmask[pass] & lrbit[it]) != 0u;
-            if (o32a) {
+            constexpr bool STATIC_OUT = (EPI & (EPI_O16 | EPI_O32)) != 0;
+            if (!STATIC_OUT && o32a) {
                 float* op = o32a + off;
                 *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -334,12 +341,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = lrelu2(v[j], post_slope2);
             }
-            if (o32b) {
+            if ((EPI & EPI_O32) || (!STATIC_OUT && o32b)) {
                 float* op = o32b + off;
                 *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (o16) {
+            if ((EPI & EPI_O16) || (!STATIC_OUT && o16)) {
                 uint4 o;
                 half2v* h = reinterpret_cast<half2v*>(&o);
 #pragma unroll
@@ -583,17 +590,23 @@ static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
         const bool odd_slope = (p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f)) ||
                                (p.post_lrelu && !(p.post_slope >= 0.f && p.post_slope <= 1.f));     // max(v, s v) form needs s in [0, 1]
         const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
-        const int e = p.seq_bias || force_generic || odd_slope ? EPI_GENERIC
-                                  : (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0) |
-                                        (rare_act ? EPI_RARE_ACT : 0);
-        switch (e) {
-            case 0: return launch_epi<TIn, BM, BN, WT, WC, 0>(p, s);
-            case EPI_RARE_ACT: return launch_epi<TIn, BM, BN, WT, WC, EPI_RARE_ACT>(p, s);
-            case EPI_RES16: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES16>(p, s);
-            case EPI_RES16 | EPI_ACC32: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES16 | EPI_ACC32>(p, s);
-            case EPI_RES32: return launch_epi<TIn, BM, BN, WT, WC, EPI_RES32>(p, s);
-            default: break;
+        const int omode = (p.out16 && !p.out32) ? EPI_O16 : ((p.out32 && !p.out16 && !p.out32_before_post) ? EPI_O32 : 0);
+        const int base = (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0) | (rare_act ? EPI_RARE_ACT : 0);
+        int e = p.seq_bias || force_generic || odd_slope ? EPI_GENERIC : (base | omode);
+#define EV_EPI_CASE(E) case (E): return launch_epi<TIn, BM, BN, WT, WC, (E)>(p, s);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            switch (e) {
+                EV_EPI_CASE(0) EV_EPI_CASE(EPI_O16) EV_EPI_CASE(EPI_O32)
+                EV_EPI_CASE(EPI_RARE_ACT) EV_EPI_CASE(EPI_RARE_ACT | EPI_O16)
+                EV_EPI_CASE(EPI_RES16) EV_EPI_CASE(EPI_RES16 | EPI_O16) EV_EPI_CASE(EPI_RES16 | EPI_O32)
+                EV_EPI_CASE(EPI_RES16 | EPI_ACC32) EV_EPI_CASE(EPI_RES16 | EPI_ACC32 | EPI_O16) EV_EPI_CASE(EPI_RES16 | EPI_ACC32 | EPI_O32)
+                EV_EPI_CASE(EPI_RES32) EV_EPI_CASE(EPI_RES32 | EPI_O32)
+                default: break;
+            }
+            if (e == EPI_GENERIC) break;
+            e = (e & (EPI_O16 | EPI_O32)) ? (e & ~(EPI_O16 | EPI_O32)) : EPI_GENERIC;    // drop the static-output flag, then give up
         }
+#undef EV_EPI_CASE
     }
     launch_epi<TIn, BM, BN, WT, WC, EPI_GENERIC>(p, s);
 }
