@@ -53,6 +53,7 @@ class ev_conv_gemm_desc(C.Structure):
         ("out_scale", C.c_float), ("acc32", C.c_void_p), ("ldacc", C.c_int), ("post_lrelu", C.c_int),
         ("post_slope", C.c_float), ("out16", C.c_void_p), ("out32", C.c_void_p), ("ldo", C.c_int),
         ("out32_before_post", C.c_int), ("reserved0", C.c_int),
+        ("add16_a", C.c_void_p), ("add16_b", C.c_void_p), ("ldadd", C.c_int), ("reserved1", C.c_int),
     ]
 
 

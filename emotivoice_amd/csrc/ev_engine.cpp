@@ -411,7 +411,7 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
     return 0;
 }
 
-struct VocBufs { Buf pre, xu[4], tmp, rba, rbb, nxt[4], mrf32, wavrows; Buf mrf_tap[4]; Buf pre_tap; };
+struct VocBufs { Buf pre, xu[4], tmp, rba, rbb, nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap; };
 
 // HiFi-GAN generator (reference models/hifigan/models.py:115-131) on channels-last fp16 rows.
 int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs& vb, bool keep) {
@@ -468,10 +468,17 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                     xcur = dst;
                 } else {
                     // MRF: xs += resblock(x); x = xs / num_kernels (models.py:121-126), then the next leaky_relu
+                    // With three ResBlocks (the reference config) the first two scaled branches are kept in fp16 and the third adds
+                    // them in its fp32 epilogue: half the HBM traffic of an fp32 running sum, and the two extra fp16 roundings are of
+                    // the size of the one the stage output gets anyway.  Any other count uses the fp32 accumulator.
                     p.out_scale = 1.0f / (float)c.n_rb;
-                    if (j > 0) { p.acc32 = (const float*)vb.mrf32.p; p.ldacc = cout; }
+                    const bool mrf16 = (c.n_rb == 3);
+                    if (mrf16) {
+                        if (j == 2) { p.add16_a = vb.mrf16a.p; p.add16_b = vb.mrf16b.p; p.ldadd = cout; }
+                    } else if (j > 0) { p.acc32 = (const float*)vb.mrf32.p; p.ldacc = cout; }
                     if (j + 1 < c.n_rb) {
-                        p.out32 = (float*)vb.mrf32.p;
+                        if (mrf16) p.out16 = (j == 0) ? vb.mrf16a.p : vb.mrf16b.p;
+                        else p.out32 = (float*)vb.mrf32.p;
                     } else {
                         p.post_lrelu = 1; p.post_slope = last_stage ? 0.01f : 0.1f;   // models.py:118 / :127
                         p.out16 = vb.nxt[i].p;
@@ -531,7 +538,8 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
         for (int i = 0; i < c.n_up; ++i) { vb.xu[i] = shared_xu; vb.nxt[i] = shared_nxt[i & 1]; }
     }
     auto mk2 = [&](size_t es) { Buf b; const size_t pad = (size_t)PAD_ROWS * 512 * es; b.bytes = max_elems * es; b.base = ap.take(pad + b.bytes + pad); b.p = ap.dry ? nullptr : b.base + pad; return b; };
-    vb.tmp = mk2(2); vb.rba = mk2(2); vb.rbb = mk2(2); vb.mrf32 = mk2(4);
+    vb.tmp = mk2(2); vb.rba = mk2(2); vb.rbb = mk2(2);
+    if (c.n_rb == 3) { vb.mrf16a = mk2(2); vb.mrf16b = mk2(2); } else vb.mrf32 = mk2(4);
     vb.wavrows = ap.rows((size_t)Rf * total_up(c), 1, 4);
 }
 

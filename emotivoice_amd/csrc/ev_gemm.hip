@@ -65,6 +65,21 @@ __device__ __forceinline__ f32x2 lrelu2(f32x2 v, f32x2 slope2) {
     return f32x2{max_raw(v[0], t[0]), max_raw(v[1], t[1])};
 }
 
+// GELU for the fp16-output epilogue: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, two orders below the fp16 rounding
+// of the stored result), branch-free: ~14 VALU + v_rcp + v_exp instead of libm erff's divergent range split (which made the
+// decoder's conv1 GEMM 2.6x slower than its equally large conv2).  The fp32 kernels keep the exact erff (apply_act).
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float a = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(a, 0.3275911f * 0.70710678118654752440f, 1.0f));
+    float pl = fmaf(t, 1.061405429f, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(v * v * (-0.5f * 1.44269504088896340736f));
+    const float q = 0.5f * v * (pl * t * e);            // = 0.5 v erfc(|v| / sqrt 2)
+    return v > 0.f ? v - q : q;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
@@ -154,6 +169,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ConvGemmParams& p, f32x4
                     const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
                     v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                 }
+                if (p.add16_a) {
+#pragma unroll
+                    for (int ab = 0; ab < 2; ++ab) {
+                        const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(ab ? p.add16_b : p.add16_a) + (long)t * p.ldadd + co);
+                        const __half2* h = reinterpret_cast<const __half2*>(&r);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); v[2 * e] += f.x; v[2 * e + 1] += f.y; }
+                    }
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -216,7 +240,7 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 // pass p+1 are requested before the stores of pass p, (d) row masking is a select, not a branch.
 // RARE_ACT: relu / gelu / tanh (runtime switch).  O16 / O32: exactly one fp16 / one fp32 (after post) output, so that the number
 // of stores per iteration is a compile-time constant and the counted vmcnt waits of the prefetches never drain them.
-enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64 };
+enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64, EPI_ADD16 = 128 };
 __device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
 template <int MT, int NT, int EPI>
@@ -236,7 +260,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     uint8_t vld[NP];
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) vld[pass] = vptr[(t0 + pass * 32 + (lane & 31)) >> vshift];
-    uint4 r16[2][IT];
+    uint4 r16[2][IT], a16[2][IT][2];
     float4 r32[2][IT][2], a32[2][IT][2];
 #define EV_EPI_PREFETCH(PASS)                                                                                              \
     _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                                                    \
@@ -252,6 +276,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             const float* ap_ = p.acc32 + t_ * p.ldacc + co;                                                                \
             a32[(PASS) & 1][it][0] = *reinterpret_cast<const float4*>(ap_);                                                \
             a32[(PASS) & 1][it][1] = *reinterpret_cast<const float4*>(ap_ + 4);                                            \
+        }                                                                                                                  \
+        if constexpr (EPI & EPI_ADD16) {                                                                                   \
+            a16[(PASS) & 1][it][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_a) + t_ * p.ldadd + co); \
+            a16[(PASS) & 1][it][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_b) + t_ * p.ldadd + co); \
         }                                                                                                                  \
     }
     EV_EPI_PREFETCH(0)
@@ -309,8 +337,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += bias2[j];
             if constexpr (EPI & EPI_RARE_ACT) {
+                if (act == ACT_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j][0] = apply_act(v[j][0], act, 0.f); v[j][1] = apply_act(v[j][1], act, 0.f); }
+                    for (int j = 0; j < 4; ++j) { v[j][0] = gelu_fast(v[j][0]); v[j][1] = gelu_fast(v[j][1]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j][0] = apply_act(v[j][0], act, 0.f); v[j][1] = apply_act(v[j][1], act, 0.f); }
+                }
             } else if (act == ACT_LRELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = lrelu2(v[j], act_slope2);
@@ -329,6 +362,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             if constexpr (EPI & EPI_ACC32) {
                 const float4 r0 = a32[pass & 1][it][0], r1 = a32[pass & 1][it][1];
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
+            }
+            if constexpr (EPI & EPI_ADD16) {
+                const half2v* ha = reinterpret_cast<const half2v*>(&a16[pass & 1][it][0]);
+                const half2v* hb = reinterpret_cast<const half2v*>(&a16[pass & 1][it][1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += __builtin_convertvector(ha[j], f32x2) + __builtin_convertvector(hb[j], f32x2);
             }
             const bool valid = (vmask[pass] & lrbit[it]) != 0u;
             constexpr bool STATIC_OUT = (EPI & (EPI_O16 | EPI_O32)) != 0;
@@ -372,7 +411,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 __device__ __forceinline__ int swz(int row, int part) { return row * 64 + ((part ^ ((row >> 1) & 3)) << 4); }
 
 template <typename TIn, int BM, int BN, int WT, int WC, int EPI>
-__global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & EPI_ACC32)) ? 2 : 3) void conv_gemm_kernel(const ConvGemmParams p EV_TRACE_ARG) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & (EPI_ACC32 | EPI_ADD16))) ? 2 : 3) void conv_gemm_kernel(const ConvGemmParams p EV_TRACE_ARG) {
     constexpr int ES = sizeof(TIn);
     constexpr int TT = BM / WT, TC = BN / WC, MT = TT / 16, NT = TC / 16;
     constexpr int SLAB = BM + MAX_SPAN;              // rows staged per K-chunk (>= BM + (taps-1)*dil, multiple of 64)
@@ -591,7 +630,8 @@ static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
                                (p.post_lrelu && !(p.post_slope >= 0.f && p.post_slope <= 1.f));     // max(v, s v) form needs s in [0, 1]
         const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
         const int omode = (p.out16 && !p.out32) ? EPI_O16 : ((p.out32 && !p.out16 && !p.out32_before_post) ? EPI_O32 : 0);
-        const int base = (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0) | (rare_act ? EPI_RARE_ACT : 0);
+        const int base = (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0) | (rare_act ? EPI_RARE_ACT : 0) |
+                         (p.add16_a ? EPI_ADD16 : 0);
         int e = p.seq_bias || force_generic || odd_slope ? EPI_GENERIC : (base | omode);
 #define EV_EPI_CASE(E) case (E): return launch_epi<TIn, BM, BN, WT, WC, (E)>(p, s);
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -599,7 +639,7 @@ static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
                 EV_EPI_CASE(0) EV_EPI_CASE(EPI_O16) EV_EPI_CASE(EPI_O32)
                 EV_EPI_CASE(EPI_RARE_ACT) EV_EPI_CASE(EPI_RARE_ACT | EPI_O16)
                 EV_EPI_CASE(EPI_RES16) EV_EPI_CASE(EPI_RES16 | EPI_O16) EV_EPI_CASE(EPI_RES16 | EPI_O32)
-                EV_EPI_CASE(EPI_RES16 | EPI_ACC32) EV_EPI_CASE(EPI_RES16 | EPI_ACC32 | EPI_O16) EV_EPI_CASE(EPI_RES16 | EPI_ACC32 | EPI_O32)
+                EV_EPI_CASE(EPI_RES16 | EPI_ADD16) EV_EPI_CASE(EPI_RES16 | EPI_ADD16 | EPI_O16)     /* (acc32: generic epilogue) */
                 EV_EPI_CASE(EPI_RES32) EV_EPI_CASE(EPI_RES32 | EPI_O32)
                 default: break;
             }
@@ -808,7 +848,8 @@ static void launch_split(const ConvGemmParams& p, hipStream_t s) {
 // HBM traffic per pair: read x once (+ the residual re-read, an L2 hit), write once -- vs 5 tensor passes layer-wise.
 __device__ char g_store_trash[64 * 64];     // masked lanes of the fused kernel's stores land here (no exec-masked branch)
 
-template <int K, bool HAS_ACC>
+// ACCMODE: 0 = none, 1 = fp32 accumulate-in (epi.acc32), 2 = two fp16 addends (epi.add16_a / add16_b)
+template <int K, int ACCMODE>
 __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPairParams p) {
     // 8 waves x 32 rows, one persistent block per CU.  The memory instruction stream of the tile loop is straight-line: the
     // first version loaded row_valid bytes / MRF rows inside runtime-flag branches and an exec-masked third slab chunk, and
@@ -934,10 +975,14 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
         for (int it = 0; it < 2; ++it) {
             const int t = min(m0 + wave * 32 + it * 16 + er, t_end - 1);
             resv[it] = *reinterpret_cast<const uint4*>(xg + (long)t * x_pitch + eg * 16);
-            if constexpr (HAS_ACC) {
+            if constexpr (ACCMODE == 1) {
                 const float* ap = e.acc32 + (long)t * e.ldacc + eco;
                 accin[it][0] = *reinterpret_cast<const float4*>(ap);
                 accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
+            }
+            if constexpr (ACCMODE == 2) {        // the same 8 registers per row hold the two fp16 addends
+                *reinterpret_cast<uint4*>(&accin[it][0]) = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(e.add16_a) + (long)t * e.ldadd + eco);
+                *reinterpret_cast<uint4*>(&accin[it][1]) = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(e.add16_b) + (long)t * e.ldadd + eco);
             }
         }
         uint8_t vb_next;
@@ -1035,9 +1080,15 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
             const half2v* hh = reinterpret_cast<const half2v*>(&resv[it]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = (v[q] + b2v[q] + __builtin_convertvector(hh[q], f32x2)) * out_scale2;
-            if constexpr (HAS_ACC) {
+            if constexpr (ACCMODE == 1) {
                 v[0] += f32x2{accin[it][0].x, accin[it][0].y}; v[1] += f32x2{accin[it][0].z, accin[it][0].w};
                 v[2] += f32x2{accin[it][1].x, accin[it][1].y}; v[3] += f32x2{accin[it][1].z, accin[it][1].w};
+            }
+            if constexpr (ACCMODE == 2) {
+                const half2v* ha = reinterpret_cast<const half2v*>(&accin[it][0]);
+                const half2v* hb = reinterpret_cast<const half2v*>(&accin[it][1]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += __builtin_convertvector(ha[q], f32x2) + __builtin_convertvector(hb[q], f32x2);
             }
             if (o32a) {
                 float* op = rowok ? o32a + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
@@ -1085,8 +1136,9 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
         if (n_cu <= 0) n_cu = 256;
         // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
 #define EV_PAIR_ATTR(KK)                                                                                              \
-    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK)); \
-    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK));
+    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK)); \
+    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK)); \
+    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK));
         EV_PAIR_ATTR(3) EV_PAIR_ATTR(7) EV_PAIR_ATTR(11)
 #undef EV_PAIR_ATTR
     }
@@ -1096,8 +1148,9 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
     const size_t lds = pair_lds_bytes(p.k);
 #define EV_PAIR_LAUNCH(KK)                                                                                          \
     case KK:                                                                                                        \
-        if (p.epi.acc32) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, true>), dim3(grid), dim3(512), lds, s, p); \
-        else hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, false>), dim3(grid), dim3(512), lds, s, p);           \
+        if (p.epi.add16_a) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 2>), dim3(grid), dim3(512), lds, s, p);  \
+        else if (p.epi.acc32) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 1>), dim3(grid), dim3(512), lds, s, p); \
+        else hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 0>), dim3(grid), dim3(512), lds, s, p);             \
         break;
     switch (p.k) {
         EV_PAIR_LAUNCH(3) EV_PAIR_LAUNCH(7) EV_PAIR_LAUNCH(11)

@@ -11,7 +11,7 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LRELU = 3, ACT_TANH = 4
 enum DType { DT_F16 = 0, DT_F32 = 1, DT_F32S = 2 };   // F32S: fp32 activations, fp16 hi/lo split weights (ConvGemmParams::W / W_lo)
 
 // out[m, n] = post( scale * ( act( sum_{tap,k} pro(A[m + (tap-center)*dil, k]) * W[n][tap][k] + bias[n] )
-//                              + seq_bias[row_seq[m]][n] + res[m, n] ) + acc32[m, n] )
+//                              + seq_bias[row_seq[m]][n] + res[m, n] ) + acc32[m, n] + add16_a[m, n] + add16_b[m, n] )
 // rows with row_valid[m >> valid_shift] == 0 are written as exact zeros.
 // Channels-last activations ([rows][channels]); the conv over time is an implicit GEMM whose
 // M dimension is time.  Reference ops covered: nn.Linear, Conv1d (any k / dilation, "same" pad),
@@ -34,6 +34,9 @@ struct ConvGemmParams {
     void* out16; float* out32; int ldo;          // either / both outputs
     int out32_before_post;                       // out32 receives the value BEFORE post_lrelu (stage taps)
     int reserved0;                               // (was: ablation switches used while tuning)
+    const void* add16_a; const void* add16_b; int ldadd;   // two fp16 tensors added after scaling (the MRF sum of three ResBlocks
+                                                 // with the first two branches kept in fp16: half the traffic of acc32), or null
+    int reserved1;
 };
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
 

@@ -16,7 +16,7 @@ extern "C" {
  * linear / conv1d / conv_transpose1d, i.e. the ops behind reference modules/encoder.py:50-52,72-109,
  * modules/variance.py:41-46 and models/hifigan/models.py:50-57,116-128.
  *   out[m,n] = post( scale * ( act( sum_{tap,k} pro(A[m+(tap-center)*dil,k]) * W[n][tap][k] + bias[n] )
- *                               + seq_bias[row_seq[m]][n] + res[m,n] ) + acc32[m,n] ), invalid rows -> 0
+ *                               + seq_bias[row_seq[m]][n] + res[m,n] ) + acc32[m,n] + add16_a[m,n] + add16_b[m,n] ), invalid rows -> 0
  * Field order and types mirror ev::ConvGemmParams exactly. */
 typedef struct ev_conv_gemm_desc {
     int dtype;                 /* 0: fp16 operands (MFMA 16x16x32 f16), 1: fp32 operands (MFMA 16x16x4 f32),
@@ -37,13 +37,16 @@ typedef struct ev_conv_gemm_desc {
     void* out16; float* out32; int ldo;
     int out32_before_post;
     int reserved0;
+    const void* add16_a; const void* add16_b; int ldadd;   /* two fp16 [M][N] tensors added after scaling (both or neither), or NULL */
+    int reserved1;
 } ev_conv_gemm_desc;
 
 int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* hip_stream);
 
 /* Fused HiFi-GAN ResBlock1 pair for C = 32: xt = lrelu(c1(lrelu(x)) + b1); out = epi(c2(xt) + b2 + x)
  * (reference models/hifigan/models.py:50-57).  `epi` uses the ev_conv_gemm_desc fields bias (= b2), res (= x), res_dtype,
- * ldres, row_valid, valid_shift, out_scale, acc32, ldacc, post_lrelu, post_slope, out16, out32, ldo, out32_before_post. */
+ * ldres, row_valid, valid_shift, out_scale, acc32, ldacc, add16_a, add16_b, ldadd (acc32 and add16 are mutually exclusive here),
+ * post_lrelu, post_slope (in [0, 1]), out16, out32, ldo, out32_before_post. */
 typedef struct ev_res_pair_desc {
     const void* x; int ldx;
     const void* w1; const float* b1;

@@ -36,7 +36,7 @@ def _padded(rows, cols, dtype, fill=None):
 
 def _run_conv(lib, x_view, w_torch, bias, *, dtype, taps, dil, center, row_valid=None, valid_shift=0, act=0, act_slope=0.0,
               pro_slope=None, res=None, scale=1.0, acc32=None, post_slope=None, seq_bias=None, row_seq=None,
-              want16=True, want32=True, before_post=False):
+              want16=True, want32=True, before_post=False, add16=None):
     from emotivoice_amd import _ffi
     M, K = x_view.shape
     N = w_torch.shape[0]
@@ -60,6 +60,8 @@ def _run_conv(lib, x_view, w_torch, bias, *, dtype, taps, dil, center, row_valid
     d.out_scale = scale
     if acc32 is not None:
         d.acc32, d.ldacc = acc32.data_ptr(), acc32.stride(0)
+    if add16 is not None:
+        d.add16_a, d.add16_b, d.ldadd = add16[0].data_ptr(), add16[1].data_ptr(), add16[0].stride(0)
     if post_slope is not None:
         d.post_lrelu, d.post_slope = 1, post_slope
     out16 = torch.full((M, N), 7.0, device="cuda", dtype=torch.float16) if want16 else None
@@ -158,6 +160,61 @@ def test_conv_gemm_full_epilogue(lib):
     assert float(o32[~vrow].abs().max()) == 0.0 and float(o16[~vrow].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("C_,taps,outs", [(64, 7, "16"), (64, 7, "32"), (128, 3, "16"), (128, 11, "both"), (32, 3, "16")])
+def test_conv_gemm_mrf16_and_static_outputs(lib, C_, taps, outs):
+    """The specialised epilogues of the frame-rate path: one fp16 output / one fp32 output (compile-time store count), fp16
+    residual, and the MRF sum with the first two ResBlock branches as fp16 addends (add16_a/b) instead of an fp32 accumulator
+    (models/hifigan/models.py:121-127).  Same reference as the generic epilogue."""
+    torch.manual_seed(7 + C_ + taps)
+    M, dil = 1024, 1
+    full, x = _padded(M, C_, torch.float16)
+    valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
+    valid[:3] = 0
+    valid[50:53] = 0
+    valid[-2:] = 0
+    vrow = valid.repeat_interleave(8).bool()
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x[~vrow] = 0
+    w = (torch.randn(C_, C_, taps, device="cuda") / math.sqrt(C_ * taps)).half()
+    bias = torch.randn(C_, device="cuda")
+    res = torch.randn(M, C_, device="cuda").half()
+    a16, b16 = torch.randn(M, C_, device="cuda").half(), torch.randn(M, C_, device="cuda").half()
+    c = (taps - 1) // 2
+    m = vrow.cpu()
+    base = _ref_conv(x.float(), w, bias, dil, c, taps)
+    # (a) conv2 of a non-final pair: residual only
+    ref = base + res.float().cpu()
+    ref[~m] = 0
+    o16, o32 = _run_conv(lib, x, w, bias, dtype=0, taps=taps, dil=dil, center=c, row_valid=valid, valid_shift=3, res=res,
+                         want16=outs != "32", want32=outs != "16")
+    if o32 is not None:
+        assert _rel(o32.cpu(), ref) < 2e-5
+        assert float(o32[~vrow].abs().max()) == 0.0
+    if o16 is not None:
+        assert _rel(o16.float().cpu(), ref) < 6e-4
+        assert float(o16[~vrow].float().abs().max()) == 0.0
+    # (b) conv2 of the last pair of the last ResBlock: scale, two fp16 addends, post leaky-relu
+    ref = (base + res.float().cpu()) * (1.0 / 3.0) + a16.float().cpu() + b16.float().cpu()
+    ref_post = _lrelu(ref, 0.1)
+    ref[~m] = 0
+    ref_post[~m] = 0
+    o16, o32 = _run_conv(lib, x, w, bias, dtype=0, taps=taps, dil=dil, center=c, row_valid=valid, valid_shift=3, res=res,
+                         scale=1.0 / 3.0, add16=(a16, b16), post_slope=0.1, want16=True, want32=outs == "both", before_post=True)
+    assert _rel(o16.float().cpu(), ref_post) < 6e-4
+    assert float(o16[~vrow].float().abs().max()) == 0.0
+    if o32 is not None:
+        assert _rel(o32.cpu(), ref) < 2e-5
+    # (c) conv1: leaky-relu prologue + activation, fp16 output only
+    xin = _lrelu(x.float(), 0.1).half().float()
+    ref = _lrelu(_ref_conv(xin, w, bias, dil, c, taps), 0.1)
+    ref[~m] = 0
+    o16, _ = _run_conv(lib, x, w, bias, dtype=0, taps=taps, dil=dil, center=c, row_valid=valid, valid_shift=3, pro_slope=0.1,
+                       act=3, act_slope=0.1, want16=True, want32=False)
+    assert _rel(o16.float().cpu(), ref) < 6e-4
+    assert float(o16[~vrow].float().abs().max()) == 0.0
+
+
 def test_conv_gemm_activations_and_seq_bias(lib):
     torch.manual_seed(4)
     M, K, N = 256, 384, 384
@@ -245,8 +302,9 @@ def test_attention_ragged(lib, is_f16):
         assert _rel(out[o:o + n].float().cpu(), ref) < (1e-3 if is_f16 else 2e-6), (n, is_f16)
 
 
-@pytest.mark.parametrize("k,dil", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5)])
-def test_fused_resblock_pair_c32(lib, k, dil):
+@pytest.mark.parametrize("k,dil,accmode", [(3, 1, "acc32"), (3, 5, "add16"), (7, 3, "acc32"), (7, 1, "add16"), (11, 1, "none"),
+                                            (11, 5, "acc32"), (11, 3, "add16")])
+def test_fused_resblock_pair_c32(lib, k, dil, accmode):
     """conv1(dil) -> leaky-relu -> conv2 + residual in one persistent kernel == the two torch convs of
     models/hifigan/models.py:50-57, incl. sequence-edge masking of the intermediate and the MRF epilogue."""
     from emotivoice_amd import _ffi
@@ -265,6 +323,7 @@ def test_fused_resblock_pair_c32(lib, k, dil):
     w2 = (torch.randn(Cc, Cc, k, device="cuda") / math.sqrt(Cc * k)).half()
     b1, b2 = torch.randn(Cc, device="cuda") * 0.1, torch.randn(Cc, device="cuda") * 0.1
     acc = torch.randn(M, Cc, device="cuda")
+    a16, b16 = torch.randn(M, Cc, device="cuda").half(), torch.randn(M, Cc, device="cuda").half()
     w1g, w2g = w1.permute(0, 2, 1).contiguous(), w2.permute(0, 2, 1).contiguous()
     out16 = torch.full((M, Cc), 7.0, device="cuda", dtype=torch.float16)
     out32 = torch.full((M, Cc), 7.0, device="cuda")
@@ -273,7 +332,15 @@ def test_fused_resblock_pair_c32(lib, k, dil):
     e = d.epi
     e.bias, e.res, e.res_dtype, e.ldres = b2.data_ptr(), x.data_ptr(), 0, Cc
     e.row_valid, e.valid_shift = valid.data_ptr(), 4
-    e.out_scale, e.acc32, e.ldacc = 1.0 / 3.0, acc.data_ptr(), Cc
+    e.out_scale = 1.0 / 3.0
+    if accmode == "acc32":
+        e.acc32, e.ldacc = acc.data_ptr(), Cc
+        addend = acc.cpu()
+    elif accmode == "add16":
+        e.add16_a, e.add16_b, e.ldadd = a16.data_ptr(), b16.data_ptr(), Cc
+        addend = a16.float().cpu() + b16.float().cpu()
+    else:
+        addend = 0.0
     e.post_lrelu, e.post_slope, e.out16, e.out32, e.ldo, e.out32_before_post = 1, 0.01, out16.data_ptr(), out32.data_ptr(), Cc, 1
     torch.cuda.synchronize()
     assert lib.ev_op_resblock_pair_c32(C.byref(d), None) == 0
@@ -282,7 +349,7 @@ def test_fused_resblock_pair_c32(lib, k, dil):
     xt = _lrelu(_ref_conv(xin, w1, b1, dil, (k - 1) // 2, k), 0.1)
     xt[~vrow.cpu()] = 0
     xt = xt.half().float()                                   # the intermediate lives in LDS as fp16
-    ref = (_ref_conv(xt, w2, b2, 1, (k - 1) // 2, k) + x.float().cpu()) * (1.0 / 3.0) + acc.cpu()
+    ref = (_ref_conv(xt, w2, b2, 1, (k - 1) // 2, k) + x.float().cpu()) * (1.0 / 3.0) + addend
     ref_post = _lrelu(ref, 0.01)
     ref[~vrow.cpu()] = 0
     ref_post[~vrow.cpu()] = 0
