@@ -654,15 +654,13 @@ static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
 template <typename TIn>
 static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
     if (p.N % 128 == 0) {
-        // 256-row tiles halve the weight-tile traffic per FLOP (the measured bottleneck of deep reductions); short reductions
-        // (few (K-chunk, tap) steps per tile) prefer 128 rows: prologue/epilogue dominate and more tiles are in flight
+        // 256-row tiles halve the weight-tile traffic per FLOP and the barrier count per MFMA; since the epilogue stopped scaling
+        // with vmcnt round trips they win on every shape measured (tools/bench_gemm.py, EV_GEMM_TILE=128/256), so 128-row
+        // tiles are only used to fill the 256 CUs when there are few tiles.  The fp32 kernel is MFMA-rate bound (1/16 of fp16),
+        // weight traffic is irrelevant there, so it only takes the big tile when there are plenty of them.
         static const char* force = getenv("EV_GEMM_TILE");            // "128" / "256": A/B switch for tools/bench_gemm.py
-        const int steps = (p.K * (int)sizeof(TIn) / 64) * p.taps;
-        bool big = steps >= 28 || p.N >= 512;
-        // few tiles: fill the 256 CUs first.  The fp32 kernel is MFMA-rate bound (1/16 of fp16), weight traffic is irrelevant
-        // there, so it only takes the big tile when there are plenty of them.
         const long tiles256 = (long)(p.M / 256) * (p.N / 128);
-        if (tiles256 < (sizeof(TIn) == 4 ? 2048 : 256)) big = false;
+        bool big = tiles256 >= (sizeof(TIn) == 4 ? 2048 : 256);
         if (force) big = force[0] == '2';
         if (big) launch_cfg<TIn, 256, 128, 2, 2>(p, s);
         else launch_cfg<TIn, 128, 128, 2, 2>(p, s);

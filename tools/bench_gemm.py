@@ -19,6 +19,8 @@ SHAPES = {
     "s0_k7": (0, RF * 8, 256, 256, 7, 3, False, True),
     "s0_k11": (0, RF * 8, 256, 256, 11, 5, False, True),
     "s0_k11_res": (0, RF * 8, 256, 256, 11, 1, True, False),
+    "s0q_k11": (0, 262144, 256, 256, 11, 5, False, True),      # exactly 4 x 512 tiles of 256 x 128 (wave-quantisation probe)
+    "s0q_k7": (0, 262144, 256, 256, 7, 3, False, True),
     "s1_k3": (0, RF * 64, 128, 128, 3, 1, False, True),
     "s1_k7": (0, RF * 64, 128, 128, 7, 3, False, True),
     "s1_k11": (0, RF * 64, 128, 128, 11, 5, False, True),

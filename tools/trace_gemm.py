@@ -27,10 +27,7 @@ NBLK = 128
 def tile_of(dtype, M, K, N, taps):
     es = 2 if dtype == 0 else 4
     if N % 128 == 0:
-        steps = (K * es // 64) * taps
-        big = steps >= 28 or N >= 512
-        if (M // 256) * (N // 128) < (2048 if es == 4 else 256):
-            big = False
+        big = (M // 256) * (N // 128) >= (2048 if es == 4 else 256)
         return (256, 128, 2, 2) if big else (128, 128, 2, 2)
     if N % 64 == 0:
         return (256, 64, 4, 1)
