@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 # algorithmic work per mel frame (SURVEY.md section 8(d) / BASELINE.md section 3)
 VOC_CONV_FLOP_PER_FRAME = 614.105e6 - 0.115e6      # every Conv1d/ConvTranspose1d of the generator except conv_post
 VOC_STAGE3_RB_FLOP_PER_FRAME = (9.437 + 22.020 + 34.603) * 1e6   # stage-3 ResBlocks (C = 32): run by the fused pair kernel
+VOC_STAGE2_K3_RB_FLOP_PER_FRAME = 18.874e6         # stage-2 k = 3 ResBlock (C = 64): run by the C = 64 fused pair kernel
 VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 AM_FLOP_PER_UTT = 51.43e9
@@ -153,13 +154,15 @@ def main():
         if os.path.exists(tpath) and B == 32 and N == 256:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         pair = stats.get("voc_resblock_pair_c32")
+        pair64 = stats.get("voc_resblock_pair_c64")
         if voc and voc["ms"] > 0:
-            # algorithmic FLOPs of what THIS kernel family executed: all generator convs minus the stage-3 ResBlocks when
-            # those ran in the fused pair kernel
-            gemm_flop = VOC_CONV_FLOP_PER_FRAME - (VOC_STAGE3_RB_FLOP_PER_FRAME if pair else 0.0)
+            # algorithmic FLOPs of what THIS kernel family executed: all generator convs minus the ResBlocks that ran in the
+            # fused pair kernels (stage 3, and the k = 3 ResBlock of stage 2)
+            gemm_flop = VOC_CONV_FLOP_PER_FRAME - (VOC_STAGE3_RB_FLOP_PER_FRAME if pair else 0.0) - \
+                (VOC_STAGE2_K3_RB_FLOP_PER_FRAME if pair64 else 0.0)
             achieved = gemm_flop * f1 / (voc["ms"] * 1e-3) / 1e12
-            voc_ms = voc["ms"] + (pair["ms"] if pair else 0.0)
-            roof = dict(bound="mfma", kernel="conv_gemm_kernel<f16> (HiFi-GAN Conv1d/ConvTranspose1d, stages 0-2 + conv_pre + ups)",
+            voc_ms = voc["ms"] + (pair["ms"] if pair else 0.0) + (pair64["ms"] if pair64 else 0.0)
+            roof = dict(bound="mfma", kernel="conv_gemm_kernel<f16> (HiFi-GAN Conv1d/ConvTranspose1d: conv_pre, ups, ResBlocks of stages 0-2 except the fused k=3 one)",
                         achieved=round(achieved, 2), peak=PEAK_MFMA_F16, unit="TFLOP/s", frac=round(achieved / PEAK_MFMA_F16, 4),
                         traffic=traffic,
                         traffic_note="HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json",
@@ -171,6 +174,9 @@ def main():
             if pair:
                 roof["fused_pair_kernel"] = dict(ms=round(pair["ms"], 3), launches=pair["launches"],
                                                  mfma_TFLOPs=round(VOC_STAGE3_RB_FLOP_PER_FRAME * f1 / (pair["ms"] * 1e-3) / 1e12, 2))
+            if pair64:
+                roof["fused_pair_kernel_c64"] = dict(ms=round(pair64["ms"], 3), launches=pair64["launches"],
+                                                     mfma_TFLOPs=round(VOC_STAGE2_K3_RB_FLOP_PER_FRAME * f1 / (pair64["ms"] * 1e-3) / 1e12, 2))
         dec = stats.get("dec_f16_gemm") or stats.get("dec_f32_gemm")
         if roof is not None and dec and "decoder" in stages:
             roof["mel_decoder"] = dict(ms=round(stages["decoder"], 3),

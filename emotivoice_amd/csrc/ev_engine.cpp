@@ -448,7 +448,8 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                 const int dil = c.rb_dils[j][d];
                 WPTR(w1, char, rb + ".c1." + std::to_string(d) + ".w16"); WPTR(b1, float, rb + ".c1." + std::to_string(d) + ".b");
                 WPTR(w2, char, rb + ".c2." + std::to_string(d) + ".w16"); WPTR(b2, float, rb + ".c2." + std::to_string(d) + ".b");
-                const bool fused = (cout == 32) && (k == 3 || k == 7 || k == 11) && !getenv("EV_NO_FUSED_PAIR");
+                // fused pair kernels: C = 32 (every k) and C = 64 with k = 3 (the HBM-bound end of the generator)
+                const bool fused = ((cout == 32 && (k == 3 || k == 7 || k == 11)) || (cout == 64 && k == 3)) && !getenv("EV_NO_FUSED_PAIR");
                 if (!fused) {
                     // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
                     p = gemm_defaults();
@@ -491,8 +492,9 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                     memset(&rp, 0, sizeof rp);
                     rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = w2; rp.M = rows_out; rp.k = k; rp.dil = dil; rp.epi = p;
                     const double fl = 2.0 * 2.0 * valid_out * cout * (double)cout * k;
-                    KScope ks(h, "voc_resblock_pair_c32", fl, valid_out * cout * 2.0 * 2.0);
-                    launch_resblock_pair_c32(rp, h->stream);
+                    KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * cout * 2.0 * 2.0);
+                    if (cout == 32) launch_resblock_pair_c32(rp, h->stream);
+                    else launch_resblock_pair_c64(rp, h->stream);
                 } else if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
             }
         }
@@ -1056,6 +1058,14 @@ int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* stream) {
     if (p.k != 3 && p.k != 7 && p.k != 11) return -2;
     if (p.epi.post_lrelu && !(p.epi.post_slope >= 0.f && p.epi.post_slope <= 1.f)) return -2;   // max(v, s v) form of leaky-relu
     launch_resblock_pair_c32(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int ev_op_resblock_pair_c64(const ev_res_pair_desc* d, void* stream) {
+    ResPairParams p;
+    memcpy(&p, d, sizeof p);
+    if (p.k != 3) return -2;
+    if (p.epi.post_lrelu && !(p.epi.post_slope >= 0.f && p.epi.post_slope <= 1.f)) return -2;
+    launch_resblock_pair_c64(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, const uint8_t* row_valid,

@@ -1157,6 +1157,291 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
 #undef EV_PAIR_LAUNCH
 }
 
+// =====================================================================================================================
+// Fused ResBlock pair, C = 64, k = 3 (HiFi-GAN stage 2: 128 samples x 64 channels per mel frame).  The k = 3 layers of that
+// stage run at the HBM roofline of their layer-wise traffic (conv1 4.4 TB/s, conv2 5.1 TB/s measured), so the only way down is
+// not to move the intermediate: same structure as the C = 32 kernel (persistent 8-wave block, conv1 -> xt in LDS -> conv2 ->
+// residual / MRF epilogue, straight-line memory stream), with the channel dimension as two 64-byte K-chunk "planes" so that
+// all of the swizzle / fragment geometry carries over.  Both weight sets (48 KB) stay in LDS for the whole kernel and are
+// read as fragments (4 per (tap, chunk), shared by the wave's two row groups); the transposed-epilogue scratch aliases the
+// slab buffer of the tile being finished (dead after conv1), which is what makes 150 KB fit.  k = 7 / 11 do not fit
+// (weights 112 / 176 KB) and stay layer-wise: they are MFMA-bound there anyway.
+template <int K, int ACCMODE>
+__global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPairParams p) {
+    constexpr int C = 64, H2 = (K - 1) / 2, BMO = 256 - 2 * H2;
+    constexpr int XROWS = 272, PLANE = XROWS * 64, XBYTES = 2 * PLANE;   // slab buffer = 2 K-chunk planes of [rows][64 B]
+    constexpr int WPL = K * C * 64, WBYTES = 2 * WPL;                    // per conv: 2 planes of [(tap, co)][64 B]
+    constexpr int EPITCH = C * 4 + 16, EBYTES = 16 * EPITCH;             // per-wave transpose scratch: 16 rows x 64 fp32
+    constexpr int XCH = (XROWS * 8 + 511) / 512;
+    static_assert(8 * EBYTES <= XBYTES && 256 + 2 * 5 * H2 + 2 * H2 <= XROWS && XCH == 5, "LDS aliasing / slab geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* W1s = smem;
+    char* W2s = smem + WBYTES;
+    char* Xa = smem + 2 * WBYTES;            // [2][2 planes][XROWS][64]
+    char* Xt = Xa + 2 * XBYTES;              // [2 planes][XROWS][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int h1 = H2 * p.dil;
+    const int x_pitch = p.ldx * 2;
+    const char* xg = reinterpret_cast<const char*>(p.x);
+    const int ntiles = (p.M + BMO - 1) / BMO;
+    const ConvGemmParams& e = p.epi;
+
+    for (int c = tid; c < K * C * 8; c += 512) {
+        const int row = c >> 3, q = c & 7, tap = row >> 6, co = row & 63, plane = q >> 2, part = q & 3;
+        const long off = ((long)(co * K + tap) * C) * 2 + q * 16;
+        *reinterpret_cast<uint4*>(W1s + plane * WPL + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w1) + off);
+        *reinterpret_cast<uint4*>(W2s + plane * WPL + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w2) + off);
+    }
+    f32x2 b1v[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b1v[a][q] = f32x2{p.b1[a * 16 + 4 * fq + 2 * q], p.b1[a * 16 + 4 * fq + 2 * q + 1]};
+    // coalesced side of the epilogue: 8 lanes per row (8 channels each), 8 rows per wave-instruction
+    const int er = lane >> 3, eg = lane & 7, eco = eg * 8;
+    const unsigned frbit = 1u << fr, erbit = 1u << er;
+    f32x2 b2v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b2v[q] = e.bias ? f32x2{e.bias[eco + 2 * q], e.bias[eco + 2 * q + 1]} : f32x2{0.f, 0.f};
+    const f32x2 out_scale2 = f32x2{e.out_scale, e.out_scale};
+    const bool has_post = e.post_lrelu != 0;
+    const f32x2 post_slope2 = f32x2{e.post_slope, e.post_slope};
+    const f32x2 slope01 = f32x2{0.1f, 0.1f};
+    __half* const o16 = reinterpret_cast<__half*>(e.out16);
+    float* const o32a = e.out32_before_post ? e.out32 : nullptr;
+    float* const o32b = e.out32_before_post ? nullptr : e.out32;
+    char* const trash = g_store_trash + lane * 64;
+
+    const uint8_t* vptr = e.row_valid ? e.row_valid : g_row_always_valid;
+    const int vshift = e.row_valid ? e.valid_shift : 31;
+#define EV_P64_VROW(TILE) ((TILE) * BMO - H2 + wave * 32 + lane)
+#define EV_P64_VLOAD(TILE, DST) { const int g_ = EV_P64_VROW(TILE); DST = vptr[min(max(g_, 0), p.M - 1) >> vshift]; }
+#define EV_P64_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_P64_VROW(TILE) >= 0 && EV_P64_VROW(TILE) < p.M)
+
+    // slab staging: chunk c = tid + 512 i -> row c >> 3, 16-byte column c & 7 (plane = column >> 2); the fifth chunk only exists
+    // for waves 0-1 (272 rows x 8 columns = 4 x 512 + 128)
+    uint4 xr[XCH];
+    const int xrow = tid >> 3, xq = tid & 7;
+    const char* const xgt = xg + xq * 16;
+    const int xdst = (xq >> 2) * PLANE + swz(xrow, xq & 3);           // + i * 64 rows: (row + 64 i) keeps the swizzle phase
+    const bool has5 = wave < 2;
+#define EV_P64_GLOAD(TILE)                                                                                 \
+    {                                                                                                      \
+        const int g0_ = (TILE) * BMO - H2 - h1 + xrow;                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            xr[i] = *reinterpret_cast<const uint4*>(xgt + (long)min(g0_ + 64 * i, p.M + 63) * x_pitch);    \
+        if (has5) xr[4] = *reinterpret_cast<const uint4*>(xgt + (long)min(g0_ + 256, p.M + 63) * x_pitch); \
+    }
+#define EV_P64_SSTORE(BUF)                                                                                 \
+    {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xdst + i * 4096) = lrelu_h8(xr[i], 0.1f);      \
+        if (has5) *reinterpret_cast<uint4*>(Xa + (BUF) * XBYTES + xdst + 4 * 4096) = lrelu_h8(xr[4], 0.1f); \
+    }
+
+    int tile = blockIdx.x;                    // grid <= ntiles
+    unsigned long long vmask;
+    {
+        uint8_t vb;
+        EV_P64_GLOAD(tile)
+        EV_P64_VLOAD(tile, vb)
+        EV_P64_SSTORE(0)
+        vmask = EV_P64_VMASK(tile, vb);
+    }
+    __syncthreads();
+    int cur = 0;
+    const int wrow0 = wave * 32 + fr;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = min(tile + (int)gridDim.x, ntiles - 1);
+        const int m0 = tile * BMO;
+        const int t_end = min(m0 + BMO, p.M);
+        // ---------------- memory requests of this iteration, oldest first: residual / MRF rows of THIS tile, slab of the NEXT
+        uint4 resv[2][2];
+        float4 accin[2][2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int t = min(m0 + wave * 32 + b * 16 + it * 8 + er, t_end - 1);
+                resv[b][it] = *reinterpret_cast<const uint4*>(xg + (long)t * x_pitch + eg * 16);
+                if constexpr (ACCMODE == 1) {
+                    const float* ap = e.acc32 + (long)t * e.ldacc + eco;
+                    accin[b][it][0] = *reinterpret_cast<const float4*>(ap);
+                    accin[b][it][1] = *reinterpret_cast<const float4*>(ap + 4);
+                }
+                if constexpr (ACCMODE == 2) {
+                    *reinterpret_cast<uint4*>(&accin[b][it][0]) = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(e.add16_a) + (long)t * e.ldadd + eco);
+                    *reinterpret_cast<uint4*>(&accin[b][it][1]) = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(e.add16_b) + (long)t * e.ldadd + eco);
+                }
+            }
+        uint8_t vb_next;
+        EV_P64_GLOAD(next)
+        EV_P64_VLOAD(next, vb_next)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[4][2];
+        // ---------------- conv1 (dilation d): 256 rows, global rows m0 - H2 + r1
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const char* Xb = Xa + cur * XBYTES;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const int r0 = wrow0 + t * p.dil;
+                const int xo = r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    uint4 xf[2], wf[4];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xb + kc * PLANE + xo + b * 16 * 64);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const uint4*>(W1s + kc * WPL + swz(t * 64 + a * 16 + fr, fq));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf[a]),
+                                                                               *reinterpret_cast<half8*>(&xf[b]), acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        // bias + leaky-relu + zero outside the utterance (conv2 must see the reference's zero padding) -> Xt (fp16, 2 planes)
+        const unsigned xtmask = (unsigned)vmask;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r1 = wrow0 + b * 16;
+            const bool valid = (xtmask & (frbit << (b * 16))) != 0u;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x2 lo = lrelu2(f32x2{acc[a][b][0], acc[a][b][1]} + b1v[a][0], slope01);
+                const f32x2 hi = lrelu2(f32x2{acc[a][b][2], acc[a][b][3]} + b1v[a][1], slope01);
+                uint2 w;
+                *reinterpret_cast<half2v*>(&w.x) = __builtin_convertvector(lo, half2v);
+                *reinterpret_cast<half2v*>(&w.y) = __builtin_convertvector(hi, half2v);
+                w.x = valid ? w.x : 0u; w.y = valid ? w.y : 0u;
+                const int c32 = (a & 1) * 16 + 4 * fq;
+                *reinterpret_cast<uint2*>(Xt + (a >> 1) * PLANE + swz(r1, c32 >> 3) + (c32 & 7) * 2) = w;
+            }
+        }
+        __syncthreads();
+        // ---------------- conv2 (dilation 1): rows m0 + r2, reads Xt rows r2 + t
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int r0 = wrow0 + t;
+            const int xo = r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                uint4 xf[2], wf[4];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xt + kc * PLANE + xo + b * 16 * 64);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const uint4*>(W2s + kc * WPL + swz(t * 64 + a * 16 + fr, fq));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf[a]),
+                                                                           *reinterpret_cast<half8*>(&xf[b]), acc[a][b], 0, 0, 0);
+            }
+        }
+        // ---------------- next tile's slab -> idle buffer (its wait comes before this tile's stores are issued)
+        __builtin_amdgcn_sched_barrier(0);
+        EV_P64_SSTORE(cur ^ 1)
+        const unsigned long long vmask_next = EV_P64_VMASK(next, vb_next);
+        // ---------------- epilogue: 16 rows at a time through the wave's scratch (inside the finished tile's slab buffer)
+        char* es = Xa + cur * XBYTES + wave * EBYTES;
+        const unsigned outmask = (unsigned)(vmask >> H2);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                *reinterpret_cast<f32x4*>(es + fr * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][b];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int lr = it * 8 + er;
+                const int t = m0 + wave * 32 + b * 16 + lr;
+                const bool rowok = t < t_end;
+                const bool valid = (outmask & (erbit << (b * 16 + it * 8))) != 0u;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32 + 16);
+                f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
+                const half2v* hh = reinterpret_cast<const half2v*>(&resv[b][it]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (v[q] + b2v[q] + __builtin_convertvector(hh[q], f32x2)) * out_scale2;
+                if constexpr (ACCMODE == 1) {
+                    v[0] += f32x2{accin[b][it][0].x, accin[b][it][0].y}; v[1] += f32x2{accin[b][it][0].z, accin[b][it][0].w};
+                    v[2] += f32x2{accin[b][it][1].x, accin[b][it][1].y}; v[3] += f32x2{accin[b][it][1].z, accin[b][it][1].w};
+                }
+                if constexpr (ACCMODE == 2) {
+                    const half2v* ha = reinterpret_cast<const half2v*>(&accin[b][it][0]);
+                    const half2v* hb = reinterpret_cast<const half2v*>(&accin[b][it][1]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += __builtin_convertvector(ha[q], f32x2) + __builtin_convertvector(hb[q], f32x2);
+                }
+                if (o32a) {
+                    float* op = rowok ? o32a + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
+                    *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (has_post) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = lrelu2(v[q], post_slope2);
+                }
+                if (o32b) {
+                    float* op = rowok ? o32b + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
+                    *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (o16) {
+                    uint4 o;
+                    half2v* h = reinterpret_cast<half2v*>(&o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = __builtin_convertvector(v[q], half2v);
+                    o.x = valid ? o.x : 0u; o.y = valid ? o.y : 0u; o.z = valid ? o.z : 0u; o.w = valid ? o.w : 0u;
+                    *reinterpret_cast<uint4*>(rowok ? reinterpret_cast<char*>(o16 + (long)t * e.ldo + eco) : trash) = o;
+                }
+            }
+        }
+        vmask = vmask_next;
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef EV_P64_GLOAD
+#undef EV_P64_SSTORE
+#undef EV_P64_VROW
+#undef EV_P64_VLOAD
+#undef EV_P64_VMASK
+}
+
+void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s) {
+    constexpr int K = 3;
+    const size_t bytes = 2 * 2 * (size_t)(K * 64 * 64) + 2 * 2 * (size_t)(272 * 64) + 2 * (size_t)(272 * 64);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        (void)hipFuncSetAttribute((const void*)resblock_pair_c64_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)resblock_pair_c64_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute((const void*)resblock_pair_c64_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    }
+    const int bmo = 256 - 2;
+    const int ntiles = (p.M + bmo - 1) / bmo;
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    if (p.epi.add16_a) hipLaunchKernelGGL((resblock_pair_c64_kernel<3, 2>), dim3(grid), dim3(512), bytes, s, p);
+    else if (p.epi.acc32) hipLaunchKernelGGL((resblock_pair_c64_kernel<3, 1>), dim3(grid), dim3(512), bytes, s, p);
+    else hipLaunchKernelGGL((resblock_pair_c64_kernel<3, 0>), dim3(grid), dim3(512), bytes, s, p);
+}
+
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {
     // preconditions are checked by the engine (ev_engine.cpp: check_gemm)
     if (p.dtype == DT_F16) launch_dt<_Float16>(p, s);

@@ -53,6 +53,8 @@ struct ResPairParams {
     ConvGemmParams epi;
 };
 void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s);
+// same pair at C = 64 (stage 2), k = 3 only: both weight sets (48 KB) stationary in LDS, x as two 64-byte K-chunk planes
+void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s);
 
 // LayerNorm over the channel dim (eps 1e-12, reference modules/encoder.py:112-127), fp32 in.
 // out16/out32 optional; if dot_w != null additionally dot_out[r] = <LN(x[r]), dot_w> + dot_b.

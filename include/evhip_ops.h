@@ -55,6 +55,8 @@ typedef struct ev_res_pair_desc {
     ev_conv_gemm_desc epi;
 } ev_res_pair_desc;
 int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* hip_stream);
+/* the same pair at C = 64 (HiFi-GAN stage 2), k = 3 only (both weight sets stay in LDS) */
+int ev_op_resblock_pair_c64(const ev_res_pair_desc* d, void* hip_stream);
 
 /* LayerNorm(eps) over channels, optional fused Linear(C,1) head (reference modules/encoder.py:112-127,
  * modules/variance.py:29-33,46). */

@@ -302,14 +302,15 @@ def test_attention_ragged(lib, is_f16):
         assert _rel(out[o:o + n].float().cpu(), ref) < (1e-3 if is_f16 else 2e-6), (n, is_f16)
 
 
-@pytest.mark.parametrize("k,dil,accmode", [(3, 1, "acc32"), (3, 5, "add16"), (7, 3, "acc32"), (7, 1, "add16"), (11, 1, "none"),
-                                            (11, 5, "acc32"), (11, 3, "add16")])
-def test_fused_resblock_pair_c32(lib, k, dil, accmode):
+@pytest.mark.parametrize("k,dil,accmode,Cc", [(3, 1, "acc32", 32), (3, 5, "add16", 32), (7, 3, "acc32", 32), (7, 1, "add16", 32),
+                                               (11, 1, "none", 32), (11, 5, "acc32", 32), (11, 3, "add16", 32),
+                                               (3, 1, "none", 64), (3, 3, "add16", 64), (3, 5, "acc32", 64)])
+def test_fused_resblock_pair(lib, k, dil, accmode, Cc):
     """conv1(dil) -> leaky-relu -> conv2 + residual in one persistent kernel == the two torch convs of
     models/hifigan/models.py:50-57, incl. sequence-edge masking of the intermediate and the MRF epilogue."""
     from emotivoice_amd import _ffi
     torch.manual_seed(100 + k + dil)
-    M, Cc = 5 * 256, 32
+    M = 5 * 256
     full, x = _padded(M, Cc, torch.float16)
     valid = torch.ones(M // 16, dtype=torch.uint8, device="cuda")
     valid[:2] = 0
@@ -343,7 +344,7 @@ def test_fused_resblock_pair_c32(lib, k, dil, accmode):
         addend = 0.0
     e.post_lrelu, e.post_slope, e.out16, e.out32, e.ldo, e.out32_before_post = 1, 0.01, out16.data_ptr(), out32.data_ptr(), Cc, 1
     torch.cuda.synchronize()
-    assert lib.ev_op_resblock_pair_c32(C.byref(d), None) == 0
+    assert (lib.ev_op_resblock_pair_c32 if Cc == 32 else lib.ev_op_resblock_pair_c64)(C.byref(d), None) == 0
     torch.cuda.synchronize()
     xin = _lrelu(x.float(), 0.1).half().float()
     xt = _lrelu(_ref_conv(xin, w1, b1, dil, (k - 1) // 2, k), 0.1)

@@ -7,7 +7,7 @@
   * profiles/<tag>_hbm_traffic.json          per-family HBM bytes of the B=32 forward from the FETCH_SIZE / WRITE_SIZE passes
                                              (FETCH_SIZE doubled, MI355X_MICROARCH.md section HBM); also written to
                                              profiles/latest_hbm_traffic.json, which bench.py reads for roofline.traffic
-  * prints the average duration of the 59 HiFi-GAN conv_gemm launches per B=32 forward (must agree with bench.py's avg_launch_ms)
+  * prints the average duration of the HiFi-GAN conv_gemm launches per B=32 forward (must agree with bench.py's avg_launch_ms)
 """
 import argparse
 import csv
@@ -17,7 +17,7 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-N_VOC = 59          # conv_pre + 4 ups + 54 ResBlock convs of stages 0-2 (stage 3 runs in the fused pair kernel)
+N_DEC = 17          # decoder launches of the same template in front of the vocoder's (4 layers x 4 GEMMs + to_mel)
 
 
 def forwards(rows):
@@ -34,8 +34,9 @@ def forwards(rows):
 
 
 def voc_gemms(fwd):
+    """HiFi-GAN launches of conv_gemm_kernel<f16>: conv_pre, 4 ups and the ResBlock convs that are not in a fused pair kernel."""
     g = [r for r in fwd if "conv_gemm_kernelIDF16" in r["Kernel_Name"]]
-    return g[-N_VOC:]
+    return g[N_DEC:]
 
 
 def pmc_family(path, counter):
@@ -49,7 +50,7 @@ def pmc_family(path, counter):
     fw = forwards(list(by_disp.values()))
     f = fw[-1]
     gem = voc_gemms(f)
-    pair = [r for r in f if "resblock_pair_c32" in r["Kernel_Name"]]
+    pair = [r for r in f if "resblock_pair_c" in r["Kernel_Name"]]
     return sum(r["value"] for r in gem), len(gem), sum(r["value"] for r in pair), len(pair)
 
 
@@ -64,14 +65,14 @@ def main():
     for f in forwards(trace):
         g = voc_gemms(f)
         avgs.append(sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in g) / len(g) / 1e6)
-    print("rocprof kernel trace: avg duration of the %d vocoder conv_gemm launches per B=32 forward (ms):" % N_VOC,
+    print("rocprof kernel trace: avg duration of the %d vocoder conv_gemm launches per B=32 forward (ms):" % len(g),
           ", ".join("%.4f" % a for a in avgs))
     fg, ng, fp, npair = pmc_family(os.path.join(OUT, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
     wg, _, wp, _ = pmc_family(os.path.join(OUT, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
     fam = {
         "conv_gemm_f16_vocoder": dict(launches=ng, fetch_size_kb_raw=fg, write_size_kb_raw=wg,
                                       hbm_bytes_per_forward=(2 * fg + wg) * 1024, hbm_bytes_per_launch=(2 * fg + wg) * 1024 / ng),
-        "resblock_pair_c32": dict(launches=npair, fetch_size_kb_raw=fp, write_size_kb_raw=wp,
+        "resblock_pair_c32_c64": dict(launches=npair, fetch_size_kb_raw=fp, write_size_kb_raw=wp,
                                   hbm_bytes_per_forward=(2 * fp + wp) * 1024, hbm_bytes_per_launch=(2 * fp + wp) * 1024 / max(npair, 1)),
     }
     frames = 32768
