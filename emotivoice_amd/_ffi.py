@@ -25,7 +25,7 @@ class ev_config(C.Structure):
         ("up_rates", C.c_int32 * 8), ("up_kernels", C.c_int32 * 8), ("up_init_ch", C.c_int32), ("n_rb", C.c_int32),
         ("rb_kernels", C.c_int32 * 8), ("rb_dils", (C.c_int32 * 4) * 8), ("n_rb_dils", C.c_int32),
         ("sample_rate", C.c_int32), ("decoder_precision", C.c_int32), ("keep_stages", C.c_int32),
-        ("token_rate_split", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -59,7 +59,7 @@ class ev_conv_gemm_desc(C.Structure):
 
 class ev_res_pair_desc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
-                ("M", C.c_int), ("k", C.c_int), ("dil", C.c_int), ("epi", ev_conv_gemm_desc)]
+                ("M", C.c_int), ("k", C.c_int), ("dil", C.c_int), ("gmin", C.c_int), ("gmax", C.c_int), ("epi", ev_conv_gemm_desc)]
 
 
 # every symbol include/evhip.h and include/evhip_ops.h declare: (restype, argtypes)

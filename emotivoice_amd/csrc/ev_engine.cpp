@@ -440,6 +440,40 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
         U *= s;
         const int shift = ilog2(U);
         const bool last_stage = (i == c.n_up - 1);
+        // Optional (ev_config.vocoder_chunk_mb > 0): the ResBlocks of a stage run on row chunks sized for the 256 MB Infinity
+        // Cache, so that a chunk's intermediates (xt, the running x of a ResBlock, the fp16 MRF branches) are re-read from the
+        // memory-side cache instead of HBM.  The isolated probe (tools/bench_chunked.py) gains 10-15 % on the HBM-bound chains
+        // with 2-4 chunks, but in the full forward every chunk size measured LOSES 1-4 % (more launches, each with its own
+        // tail: 113-251 instead of 53 conv launches), so the default is whole tensors.
+        // Overlapped tiling keeps the result bit-identical: op q of a ResBlock's 6-conv chain runs on the chunk extended by
+        // (5 - q) x 256 rows per side, more than any conv's halo (<= 25 rows; the fused pair kernels get the tensor's true
+        // bounds so that they zero-pad only at real sequence edges), so the last op's rows [a, b) only ever read
+        // rows that were recomputed from valid inputs inside this chunk; what the extensions write outside [a, b) is dead or
+        // rewritten by the neighbouring chunk.
+        int nchunks = 1;
+        if (!keep && c.vocoder_chunk_mb > 0) {
+            const double tensor_mb = (double)rows_out * cout * 2.0 / 1e6;
+            nchunks = (int)(tensor_mb / c.vocoder_chunk_mb + 0.5);
+            if (nchunks < 1) nchunks = 1;
+            if (nchunks > 64) nchunks = 64;
+        }
+        const int chunk_rows = ((rows_out + nchunks - 1) / nchunks + 255) / 256 * 256;
+        // shift every row-indexed operand of a conv call to the row range [lo, hi)
+        auto sub = [&](ConvGemmParams q, int lo, int hi) {
+            const size_t es = 2;     // all frame-rate activations of the vocoder are fp16
+            q.A = (const char*)q.A + (size_t)lo * q.lda * es;
+            if (q.res) q.res = (const char*)q.res + (size_t)lo * q.ldres * (q.res_dtype == DT_F16 ? 2 : 4);
+            if (q.acc32) q.acc32 = q.acc32 + (size_t)lo * q.ldacc;
+            if (q.add16_a) { q.add16_a = (const char*)q.add16_a + (size_t)lo * q.ldadd * 2; q.add16_b = (const char*)q.add16_b + (size_t)lo * q.ldadd * 2; }
+            if (q.out16) q.out16 = (char*)q.out16 + (size_t)lo * q.ldo * 2;
+            if (q.out32) q.out32 = q.out32 + (size_t)lo * q.ldo;
+            if (q.row_valid) q.row_valid = q.row_valid + (lo >> q.valid_shift);
+            q.M = hi - lo;
+            return q;
+        };
+        for (int a0 = 0; a0 < rows_out; a0 += chunk_rows) {
+        const int b0 = std::min(rows_out, a0 + chunk_rows);
+        const double frac = (double)(b0 - a0) / rows_out;
         for (int j = 0; j < c.n_rb; ++j) {
             const int k = c.rb_kernels[j];
             const std::string rb = "voc.rb" + std::to_string(i * c.n_rb + j);
@@ -456,7 +490,8 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                     p.dtype = DT_F16; p.A = xcur; p.lda = cout; p.W = w1; p.bias = b1; p.M = rows_out; p.N = cout; p.K = cout;
                     p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
                     p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.out16 = vb.tmp.p; p.ldo = cout;
-                    if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
+                    const int e1 = (2 * (c.n_rb_dils - 1 - d) + 1) * 256, lo1 = std::max(0, a0 - e1), hi1 = std::min(rows_out, b0 + e1);
+                    if (gemm(h, "voc_conv_gemm_f16", sub(p, lo1, hi1), valid_out * frac)) return -1;
                 }
                 // x = c2(xt) + x  (models.py:54-56)
                 p = gemm_defaults();
@@ -486,18 +521,21 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                         if (keep) { p.out32 = (float*)vb.mrf_tap[i].p; p.out32_before_post = 1; }
                     }
                 }
+                const int e2 = 2 * (c.n_rb_dils - 1 - d) * 256, lo2 = std::max(0, a0 - e2), hi2 = std::min(rows_out, b0 + e2);
+                p = sub(p, lo2, hi2);
                 if (fused) {
                     // conv1 -> LDS -> conv2 + residual / MRF epilogue in one persistent kernel (ev_gemm.hip)
                     ResPairParams rp;
                     memset(&rp, 0, sizeof rp);
-                    rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = w2; rp.M = rows_out; rp.k = k; rp.dil = dil; rp.epi = p;
-                    const double fl = 2.0 * 2.0 * valid_out * cout * (double)cout * k;
-                    KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * cout * 2.0 * 2.0);
+                    rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = w2; rp.M = p.M; rp.k = k; rp.dil = dil; rp.gmin = -lo2; rp.gmax = rows_out - lo2; rp.epi = p;
+                    const double fl = 2.0 * 2.0 * valid_out * frac * cout * (double)cout * k;
+                    KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0);
                     if (cout == 32) launch_resblock_pair_c32(rp, h->stream);
                     else launch_resblock_pair_c64(rp, h->stream);
-                } else if (gemm(h, "voc_conv_gemm_f16", p, valid_out)) return -1;
+                } else if (gemm(h, "voc_conv_gemm_f16", p, valid_out * frac)) return -1;
             }
         }
+        }   // row chunks
         prev = vb.nxt[i].p;
         ch = cout;
     }

@@ -875,6 +875,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
     const char* xg = reinterpret_cast<const char*>(p.x);
     const int ntiles = (p.M + BMO - 1) / BMO;
     const ConvGemmParams& e = p.epi;
+    const int gmin = p.gmax ? p.gmin : 0, gmax = p.gmax ? p.gmax : p.M;      // rows of x that exist (sub-range launches)
 
     for (int c = tid; c < K * C * 4; c += 512) {
         const int row = c >> 2, part = c & 3, tap = row >> 5, co = row & 31;
@@ -910,9 +911,9 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
 #define EV_PAIR_VLOAD(TILE, DST)                                                                           \
     {                                                                                                      \
         const int g_ = EV_PAIR_VROW(TILE);                                                                 \
-        DST = vptr[min(max(g_, 0), p.M - 1) >> vshift];                                                    \
+        DST = vptr[min(max(g_, gmin), gmax - 1) >> vshift];                                                \
     }
-#define EV_PAIR_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_PAIR_VROW(TILE) >= 0 && EV_PAIR_VROW(TILE) < p.M)
+#define EV_PAIR_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_PAIR_VROW(TILE) >= gmin && EV_PAIR_VROW(TILE) < gmax)
 
     uint4 xr0, xr1, xr2;
     const int xd0 = swz(tid >> 2, tid & 3), xd1 = swz((tid + 512) >> 2, tid & 3), xd2 = swz((tid + 1024) >> 2, tid & 3);
@@ -920,8 +921,8 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
     const char* const xgt = xg + (tid & 3) * 16;
     const int xrow2 = min((tid >> 2) + 256, 255 + 2 * h1 + 2 * H2);
     // rows beyond the slab the convs read (256 + 2 h1 + 2 H2 <= 316) re-read the last needed row: a cache hit, not HBM traffic
-    // (the first slab row is >= -(H2 + h1) >= -30, inside the 64 slack rows; only the upper end needs a clamp)
-#define EV_PAIR_ROW(G) min((G), p.M + 63)
+    // (the first slab row is >= gmin - (H2 + h1) >= gmin - 30, inside the 64 slack rows; only the upper end needs a clamp)
+#define EV_PAIR_ROW(G) min((G), gmax + 63)
 #define EV_PAIR_GLOAD(TILE)                                                                                \
     {                                                                                                      \
         const int g0_ = (TILE) * BMO - H2 - h1 + (tid >> 2);                                               \
@@ -1186,6 +1187,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
     const char* xg = reinterpret_cast<const char*>(p.x);
     const int ntiles = (p.M + BMO - 1) / BMO;
     const ConvGemmParams& e = p.epi;
+    const int gmin = p.gmax ? p.gmin : 0, gmax = p.gmax ? p.gmax : p.M;      // rows of x that exist (sub-range launches)
 
     for (int c = tid; c < K * C * 8; c += 512) {
         const int row = c >> 3, q = c & 7, tap = row >> 6, co = row & 63, plane = q >> 2, part = q & 3;
@@ -1216,8 +1218,8 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
     const uint8_t* vptr = e.row_valid ? e.row_valid : g_row_always_valid;
     const int vshift = e.row_valid ? e.valid_shift : 31;
 #define EV_P64_VROW(TILE) ((TILE) * BMO - H2 + wave * 32 + lane)
-#define EV_P64_VLOAD(TILE, DST) { const int g_ = EV_P64_VROW(TILE); DST = vptr[min(max(g_, 0), p.M - 1) >> vshift]; }
-#define EV_P64_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_P64_VROW(TILE) >= 0 && EV_P64_VROW(TILE) < p.M)
+#define EV_P64_VLOAD(TILE, DST) { const int g_ = EV_P64_VROW(TILE); DST = vptr[min(max(g_, gmin), gmax - 1) >> vshift]; }
+#define EV_P64_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_P64_VROW(TILE) >= gmin && EV_P64_VROW(TILE) < gmax)
 
     // slab staging: chunk c = tid + 512 i -> row c >> 3, 16-byte column c & 7 (plane = column >> 2); the fifth chunk only exists
     // for waves 0-1 (272 rows x 8 columns = 4 x 512 + 128)
@@ -1230,8 +1232,8 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
     {                                                                                                      \
         const int g0_ = (TILE) * BMO - H2 - h1 + xrow;                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
-            xr[i] = *reinterpret_cast<const uint4*>(xgt + (long)min(g0_ + 64 * i, p.M + 63) * x_pitch);    \
-        if (has5) xr[4] = *reinterpret_cast<const uint4*>(xgt + (long)min(g0_ + 256, p.M + 63) * x_pitch); \
+            xr[i] = *reinterpret_cast<const uint4*>(xgt + (long)min(g0_ + 64 * i, gmax + 63) * x_pitch);    \
+        if (has5) xr[4] = *reinterpret_cast<const uint4*>(xgt + (long)min(g0_ + 256, gmax + 63) * x_pitch); \
     }
 #define EV_P64_SSTORE(BUF)                                                                                 \
     {                                                                                                      \

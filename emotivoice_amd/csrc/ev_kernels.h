@@ -50,6 +50,9 @@ struct ResPairParams {
     const void* w1; const float* b1;    // [32][k][32] fp16
     const void* w2;
     int M, k, dil;
+    int gmin, gmax;                     // rows g of x (relative to the x pointer) that exist in the tensor: gmin <= g < gmax.  {0, M} for a
+                                        // whole tensor; a launch on a row sub-range (chunked execution) passes the tensor's real bounds so
+                                        // that only true sequence edges are zero-padded.  gmax == 0 means {0, M}.
     ConvGemmParams epi;
 };
 void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s);

@@ -66,7 +66,11 @@ typedef struct ev_config {
     int32_t keep_stages;        /* !=0: keep every Appendix-C stage tap retrievable by ev_get_stage */
     int32_t token_rate_split;   /* 1 (default): fp32 token-rate GEMMs as 3 fp16 MFMAs on hi/lo splits (fp32-level accuracy,
                                    ~4x faster); 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
-    int32_t reserved[7];
+    int32_t vocoder_chunk_mb;   /* > 0: the ResBlocks of a generator stage run on row chunks of about this many MB per fp16 tensor so
+                                   that a chunk's intermediates stay in the 256 MB Infinity Cache (bit-identical results for any
+                                   value; measured slower than whole tensors in the full forward, hence off); 0 (default): whole
+                                   tensors */
+    int32_t reserved[6];
 } ev_config;
 
 enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1 };

@@ -52,6 +52,7 @@ typedef struct ev_res_pair_desc {
     const void* w1; const float* b1;
     const void* w2;
     int M, k, dil;
+    int gmin, gmax;    /* rows of x that exist (relative to x): gmin <= g < gmax; leave both 0 for the whole tensor {0, M} */
     ev_conv_gemm_desc epi;
 } ev_res_pair_desc;
 int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* hip_stream);

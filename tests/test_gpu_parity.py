@@ -325,3 +325,23 @@ def test_chunked_vocoding_is_bit_identical(gpu):
     assert short.shape == full.shape and not np.array_equal(short, full)
     exact14 = np.concatenate(list(eng.vocoder_chunked(mel, chunk_frames=256, context=14)))
     assert np.array_equal(exact14, full)
+
+
+def test_chunked_stage_execution_is_bit_identical(gpu):
+    """The generator's ResBlocks run on row chunks sized for the Infinity Cache (ev_config.vocoder_chunk_mb, overlapped
+    tiling over the 6-conv chain of a ResBlock): any chunk size must give the same bits as whole-tensor execution, with chunk
+    borders falling inside utterances and next to the zero gaps between them."""
+    from emotivoice_amd.engine import EVEngine
+    from oracle import synth_inputs
+    _, blob, man = _weights("parity")
+    utts = synth_inputs(21, [96, 33, 120, 64, 77, 128, 50, 101], [1, 2, 3, 4, 5, 6, 7, 8])
+    outs = []
+    for mb in (0, 1, 3, 7):       # whole tensors (default) / ~1 MB chunks (dozens of chunks per stage) / ~3 MB / ~7 MB
+        eng = EVEngine(vocoder_chunk_mb=mb)
+        eng.load_blob(blob, man)
+        r = eng.synthesize(utts)
+        outs.append(r["wav"].copy())
+        eng.close()
+    assert float(np.abs(outs[0]).max()) > 0
+    for other in outs[1:]:
+        assert other.shape == outs[0].shape and np.array_equal(outs[0], other)
