@@ -100,7 +100,8 @@ def main():
     # weights: rank 0 packs, everyone receives the blob with one broadcast (RCCL over xGMI), borrowed in place
     blob_t = broadcast_blob(rank, world, local_rank, dist, dur_mode="bench")
     eng = EVEngine(device_id=local_rank, decoder_precision=args.decoder_precision,
-                   vocoder_chunk_mb=int(os.environ.get("EV_CHUNK_MB", "0")))      # tuning override; 0 = engine default
+                   vocoder_chunk_mb=int(os.environ.get("EV_CHUNK_MB", "0")),       # tuning overrides; 0 = engine default
+                   vocoder_streams=int(os.environ.get("EV_VOC_STREAMS", "0")))
     eng.load_blob_device(blob_t.data_ptr(), blob_t.numel(), keepalive=blob_t)
 
     B, N = args.batch, args.phonemes

@@ -25,7 +25,7 @@ class ev_config(C.Structure):
         ("up_rates", C.c_int32 * 8), ("up_kernels", C.c_int32 * 8), ("up_init_ch", C.c_int32), ("n_rb", C.c_int32),
         ("rb_kernels", C.c_int32 * 8), ("rb_dils", (C.c_int32 * 4) * 8), ("n_rb_dils", C.c_int32),
         ("sample_rate", C.c_int32), ("decoder_precision", C.c_int32), ("keep_stages", C.c_int32),
-        ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("vocoder_streams", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -56,6 +56,8 @@ struct ev_handle {
     ev_config cfg;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t aux[2] = {nullptr, nullptr};         // the first two ResBlocks of a generator stage run beside the third
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::string err;
     // weights
     char* wblob = nullptr; bool wblob_owned = false; size_t wbytes = 0;
@@ -233,17 +235,17 @@ hipEvent_t get_evt(ev_handle* h) {
     return h->evt_pool[h->evt_next++];
 }
 struct KScope {   // wraps one kernel launch with events when profiling is on
-    ev_handle* h; int sid = -1; hipEvent_t a{}, b{};
-    KScope(ev_handle* h_, const char* name, double flops, double bytes) : h(h_) {
+    ev_handle* h; int sid = -1; hipEvent_t a{}, b{}; hipStream_t st;
+    KScope(ev_handle* h_, const char* name, double flops, double bytes, hipStream_t s = nullptr) : h(h_), st(s ? s : h_->stream) {
         if (!h->profiling) return;
         sid = stat_id(h, name);
         h->stats[sid].launches++; h->stats[sid].flops += flops; h->stats[sid].bytes += bytes;
         a = get_evt(h); b = get_evt(h);
-        (void)hipEventRecord(a, h->stream);
+        (void)hipEventRecord(a, st);
     }
     ~KScope() {
         if (sid < 0) return;
-        (void)hipEventRecord(b, h->stream);
+        (void)hipEventRecord(b, st);
         h->pending.push_back({a, b, sid});
     }
 };
@@ -283,14 +285,14 @@ int check_gemm(ev_handle* h, const ConvGemmParams& p) {
     if (!p.out16 && !p.out32) return fail(h, "gemm: no output");
     return 0;
 }
-int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_rows) {
+int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_rows, hipStream_t st = nullptr) {
     if (check_gemm(h, p)) return -1;
     const int es = p.dtype == DT_F16 ? 2 : 4;
     const double flops = 2.0 * valid_rows * p.N * (double)p.K * p.taps;
     double bytes = valid_rows * ((double)p.K * es + (double)p.N * (p.out16 ? 2 : 0) + (double)p.N * (p.out32 ? 4 : 0)) +
                    (double)p.N * p.K * p.taps * es;
-    KScope ks(h, name, flops, bytes);
-    launch_conv_gemm(p, h->stream);
+    KScope ks(h, name, flops, bytes, st);
+    launch_conv_gemm(p, st ? st : h->stream);
     return 0;
 }
 ConvGemmParams gemm_defaults() {
@@ -411,7 +413,7 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
     return 0;
 }
 
-struct VocBufs { Buf pre, xu[4], tmp, rba, rbb, nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap; };
+struct VocBufs { Buf pre, xu[4], tmp[3], rba[3], rbb[3], nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap; };
 
 // HiFi-GAN generator (reference models/hifigan/models.py:115-131) on channels-last fp16 rows.
 int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs& vb, bool keep) {
@@ -471,6 +473,16 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
             q.M = hi - lo;
             return q;
         };
+        // The three ResBlocks of a stage only share the stage input and meet again in the MRF sum: the first two run on
+        // auxiliary streams beside the third (its last conv waits for both).  A k = 3 chain is HBM-bound and a k = 11 chain
+        // MFMA-bound, so their workgroups complement each other on a CU and fill each other's launch tails.  Profiled steps
+        // (per-launch events) and chunked execution stay on one stream.
+        const bool conc = c.n_rb == 3 && nchunks == 1 && !h->profiling && c.vocoder_streams != 1 && h->aux[0] && h->aux[1];
+        if (conc) {
+            (void)hipEventRecord(h->ev_fork, h->stream);
+            (void)hipStreamWaitEvent(h->aux[0], h->ev_fork, 0);
+            (void)hipStreamWaitEvent(h->aux[1], h->ev_fork, 0);
+        }
         for (int a0 = 0; a0 < rows_out; a0 += chunk_rows) {
         const int b0 = std::min(rows_out, a0 + chunk_rows);
         const double frac = (double)(b0 - a0) / rows_out;
@@ -478,6 +490,8 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
             const int k = c.rb_kernels[j];
             const std::string rb = "voc.rb" + std::to_string(i * c.n_rb + j);
             const void* xcur = vb.xu[i].p;
+            const int bj = conc ? j : 0;
+            hipStream_t sj = (conc && j < 2) ? h->aux[j] : h->stream;
             for (int d = 0; d < c.n_rb_dils; ++d) {
                 const int dil = c.rb_dils[j][d];
                 WPTR(w1, char, rb + ".c1." + std::to_string(d) + ".w16"); WPTR(b1, float, rb + ".c1." + std::to_string(d) + ".b");
@@ -489,17 +503,17 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                     p = gemm_defaults();
                     p.dtype = DT_F16; p.A = xcur; p.lda = cout; p.W = w1; p.bias = b1; p.M = rows_out; p.N = cout; p.K = cout;
                     p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
-                    p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.out16 = vb.tmp.p; p.ldo = cout;
+                    p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.out16 = vb.tmp[bj].p; p.ldo = cout;
                     const int e1 = (2 * (c.n_rb_dils - 1 - d) + 1) * 256, lo1 = std::max(0, a0 - e1), hi1 = std::min(rows_out, b0 + e1);
-                    if (gemm(h, "voc_conv_gemm_f16", sub(p, lo1, hi1), valid_out * frac)) return -1;
+                    if (gemm(h, "voc_conv_gemm_f16", sub(p, lo1, hi1), valid_out * frac, sj)) return -1;
                 }
                 // x = c2(xt) + x  (models.py:54-56)
                 p = gemm_defaults();
-                p.dtype = DT_F16; p.A = vb.tmp.p; p.lda = cout; p.W = w2; p.bias = b2; p.M = rows_out; p.N = cout; p.K = cout;
+                p.dtype = DT_F16; p.A = vb.tmp[bj].p; p.lda = cout; p.W = w2; p.bias = b2; p.M = rows_out; p.N = cout; p.K = cout;
                 p.taps = k; p.dil = 1; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
                 p.res = xcur; p.res_dtype = DT_F16; p.ldres = cout; p.ldo = cout;
                 if (d + 1 < c.n_rb_dils) {
-                    void* dst = (d % 2 == 0) ? vb.rba.p : vb.rbb.p;
+                    void* dst = (d % 2 == 0) ? vb.rba[bj].p : vb.rbb[bj].p;
                     p.out16 = dst;
                     xcur = dst;
                 } else {
@@ -523,17 +537,22 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                 }
                 const int e2 = 2 * (c.n_rb_dils - 1 - d) * 256, lo2 = std::max(0, a0 - e2), hi2 = std::min(rows_out, b0 + e2);
                 p = sub(p, lo2, hi2);
+                if (conc && j == 2 && d + 1 == c.n_rb_dils) {      // the MRF sum reads the other two branches
+                    (void)hipStreamWaitEvent(h->stream, h->ev_join[0], 0);
+                    (void)hipStreamWaitEvent(h->stream, h->ev_join[1], 0);
+                }
                 if (fused) {
                     // conv1 -> LDS -> conv2 + residual / MRF epilogue in one persistent kernel (ev_gemm.hip)
                     ResPairParams rp;
                     memset(&rp, 0, sizeof rp);
                     rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = w2; rp.M = p.M; rp.k = k; rp.dil = dil; rp.gmin = -lo2; rp.gmax = rows_out - lo2; rp.epi = p;
                     const double fl = 2.0 * 2.0 * valid_out * frac * cout * (double)cout * k;
-                    KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0);
-                    if (cout == 32) launch_resblock_pair_c32(rp, h->stream);
-                    else launch_resblock_pair_c64(rp, h->stream);
-                } else if (gemm(h, "voc_conv_gemm_f16", p, valid_out * frac)) return -1;
+                    KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0, sj);
+                    if (cout == 32) launch_resblock_pair_c32(rp, sj);
+                    else launch_resblock_pair_c64(rp, sj);
+                } else if (gemm(h, "voc_conv_gemm_f16", p, valid_out * frac, sj)) return -1;
             }
+            if (conc && j < 2) (void)hipEventRecord(h->ev_join[j], h->aux[j]);
         }
         }   // row chunks
         prev = vb.nxt[i].p;
@@ -578,7 +597,7 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
         for (int i = 0; i < c.n_up; ++i) { vb.xu[i] = shared_xu; vb.nxt[i] = shared_nxt[i & 1]; }
     }
     auto mk2 = [&](size_t es) { Buf b; const size_t pad = (size_t)PAD_ROWS * 512 * es; b.bytes = max_elems * es; b.base = ap.take(pad + b.bytes + pad); b.p = ap.dry ? nullptr : b.base + pad; return b; };
-    vb.tmp = mk2(2); vb.rba = mk2(2); vb.rbb = mk2(2);
+    for (int j = 0; j < (c.n_rb == 3 ? 3 : 1); ++j) { vb.tmp[j] = mk2(2); vb.rba[j] = mk2(2); vb.rbb[j] = mk2(2); }   // per ResBlock: they run concurrently
     if (c.n_rb == 3) { vb.mrf16a = mk2(2); vb.mrf16b = mk2(2); } else vb.mrf32 = mk2(4);
     vb.wavrows = ap.rows((size_t)Rf * total_up(c), 1, 4);
 }
@@ -680,6 +699,11 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
         return fail(nullptr, "ev_create: cannot create stream on device %d", device_id);
     }
     h->stream = h->own_stream;
+    for (int j = 0; j < 2; ++j) {
+        if (hipStreamCreateWithFlags(&h->aux[j], hipStreamNonBlocking) != hipSuccess) h->aux[j] = nullptr;
+        (void)hipEventCreateWithFlags(&h->ev_join[j], hipEventDisableTiming);
+    }
+    (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     *out = h;
     return 0;
 }
@@ -694,6 +718,8 @@ void ev_destroy(ev_handle* h) {
     if (h->wblob && h->wblob_owned) (void)hipFree(h->wblob);
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
     for (auto& kv : h->region_evt) { (void)hipEventDestroy(kv.second.first); (void)hipEventDestroy(kv.second.second); }
+    for (int j = 0; j < 2; ++j) { if (h->aux[j]) (void)hipStreamDestroy(h->aux[j]); if (h->ev_join[j]) (void)hipEventDestroy(h->ev_join[j]); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

@@ -15,7 +15,7 @@ class EVError(RuntimeError):
 
 
 def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages: bool = False,
-                   token_rate: str = "split", vocoder_chunk_mb: int = 0) -> _ffi.ev_config:
+                   token_rate: str = "split", vocoder_chunk_mb: int = 0, vocoder_streams: int = 0) -> _ffi.ev_config:
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
     for f in ("n_vocab", "n_speaker", "n_mels", "hidden", "heads", "enc_layers", "dec_layers", "ffn_kernel", "bert_dim",
@@ -34,6 +34,7 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages
     cfg.decoder_precision = {"f16": _ffi.EV_PREC_F16, "f32": _ffi.EV_PREC_F32}[decoder_precision]
     cfg.keep_stages = 1 if keep_stages else 0
     cfg.vocoder_chunk_mb = int(vocoder_chunk_mb)
+    cfg.vocoder_streams = int(vocoder_streams)
     cfg.token_rate_split = {"split": 1, "f32": 0}[token_rate]
     return cfg
 
@@ -42,11 +43,12 @@ class EVEngine:
     """One handle = one GPU + one stream + one workspace (include/evhip.h).  Not thread-safe."""
 
     def __init__(self, shapes: Optional[EVShapes] = None, device_id: int = 0, decoder_precision: str = "f16",
-                 keep_stages: bool = False, token_rate: str = "split", vocoder_chunk_mb: int = 0):
+                 keep_stages: bool = False, token_rate: str = "split", vocoder_chunk_mb: int = 0,
+                 vocoder_streams: int = 0):
         self.shapes = shapes or EVShapes()
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
-        cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate, vocoder_chunk_mb)
+        cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate, vocoder_chunk_mb, vocoder_streams)
         if self._lib.ev_create(device_id, C.byref(cfg), C.byref(self._h)) != 0:
             raise EVError(self._lib.ev_last_error(None).decode())
         self.device_id = device_id

@@ -70,7 +70,9 @@ typedef struct ev_config {
                                    that a chunk's intermediates stay in the 256 MB Infinity Cache (bit-identical results for any
                                    value; measured slower than whole tensors in the full forward, hence off); 0 (default): whole
                                    tensors */
-    int32_t reserved[6];
+    int32_t vocoder_streams;    /* 0 (default): the three ResBlocks of a generator stage run concurrently (two internal streams beside
+                                   the handle's); 1: everything on the handle's stream */
+    int32_t reserved[5];
 } ev_config;
 
 enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1 };
