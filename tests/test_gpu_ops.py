@@ -160,17 +160,21 @@ def test_conv_gemm_full_epilogue(lib):
     assert float(o32[~vrow].abs().max()) == 0.0 and float(o16[~vrow].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("C_,taps,outs", [(64, 7, "16"), (64, 7, "32"), (128, 3, "16"), (128, 11, "both"), (32, 3, "16")])
-def test_conv_gemm_mrf16_and_static_outputs(lib, C_, taps, outs):
+@pytest.mark.parametrize("C_,taps,outs,M", [(64, 7, "16", 1024), (64, 7, "32", 1024), (128, 3, "16", 1024), (128, 11, "both", 1024),
+                                             (32, 3, "16", 1024),
+                                             # >= 256 tiles of 256 x 128: the paired-step kernel (two taps per barrier)
+                                             (128, 3, "16", 65536), (128, 7, "16", 65536), (128, 11, "16", 65536), (256, 7, "16", 32768)])
+def test_conv_gemm_mrf16_and_static_outputs(lib, C_, taps, outs, M):
     """The specialised epilogues of the frame-rate path: one fp16 output / one fp32 output (compile-time store count), fp16
     residual, and the MRF sum with the first two ResBlock branches as fp16 addends (add16_a/b) instead of an fp32 accumulator
     (models/hifigan/models.py:121-127).  Same reference as the generic epilogue."""
     torch.manual_seed(7 + C_ + taps)
-    M, dil = 1024, 1
+    dil = 1 if M == 1024 else (taps - 1) // 2      # the big cases also use the ResBlock dilations 1 / 3 / 5
     full, x = _padded(M, C_, torch.float16)
     valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
     valid[:3] = 0
     valid[50:53] = 0
+    valid[M // 16:M // 16 + 4] = 0
     valid[-2:] = 0
     vrow = valid.repeat_interleave(8).bool()
     full[:PAD] = 0

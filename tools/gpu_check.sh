@@ -18,7 +18,7 @@ for st in $STAGES; do
             timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_write" -o w -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --cpu-utts 0 > "$GRAFT_REPO_ROOT/gpurun_out/pmc_write.log" 2>&1
             echo "pmc rc=$?"; cd "$GRAFT_REPO_ROOT";;
     dist2)  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --force-device 0 --batch 8 > gpurun_out/dist2.log 2>&1; echo "dist2 rc=$?"; tail -n 3 gpurun_out/dist2.log | cut -c1-600;;
-    prof)   cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --cpu-utts 0 > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$GRAFT_REPO_ROOT";;
+    prof)   cd /tmp && export TMPDIR=/tmp && EV_VOC_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --cpu-utts 0 > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$GRAFT_REPO_ROOT";;
   esac
 done
 tail -n 30 gpurun_out/ops.log gpurun_out/parity.log gpurun_out/gen.log gpurun_out/smoke.log gpurun_out/bench.log 2>/dev/null | tail -n 120
