@@ -397,6 +397,102 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
     }
 }
 
+// ---- fp32 MFMA flash attention (text encoder, strict-fp32 decoder): exact fp32 products on v_mfma_f32_16x16x4_f32.
+// The VALU kernel above keeps one query per lane and walks the keys serially (142 us per encoder layer at 32 x 256 tokens,
+// a pure latency chain); here one wave owns 16 queries and a 16-key tile is two small GEMMs:
+//     S^T[key][query] = K_tile . Q^T        (12 MFMAs: d_k = 48 = 12 x 4)
+//     O^T[d][query]  += V_tile^T . P^T      (3 d-tiles x 4 MFMAs)
+// computed transposed so that the probabilities never leave the registers: the C layout of S^T gives lane (query = lane % 16,
+// g = lane / 16) the keys 4 g + i, and the B operand of the second product wants, at reduction step i, exactly
+// "key 4 g + i of query lane % 16" when the step's four reduction slots are mapped to keys {i, 4 + i, 8 + i, 12 + i}.  The
+// reduction index of the first product is permuted the same way (slot g of step j = dim 12 g + j), which makes the Q / K
+// operands three contiguous float4 loads per lane.  Online softmax per query: 2 cross-lane shuffles per tile.
+template <int DK>
+__global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParams p) {
+    static_assert(DK == 48, "d_k = 48: 12 reduction steps of 4, 3 output tiles of 16");
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = p.seq_len[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    if (q0 >= len) return;
+    const int fr = lane & 15, g = lane >> 4;
+    const long row0 = p.seq_off[b];
+    const float* base = reinterpret_cast<const float*>(p.qkv);
+    const float scale = 1.0f / sqrtf((float)DK);
+
+    float qv[12];
+    {
+        const int qi = min(q0 + fr, len - 1);
+        const float4* qp = reinterpret_cast<const float4*>(base + (row0 + qi) * p.ld + h * DK + g * 12);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float4 t = qp[c]; qv[4 * c] = t.x * scale; qv[4 * c + 1] = t.y * scale; qv[4 * c + 2] = t.z * scale; qv[4 * c + 3] = t.w * scale; }
+    }
+    f4 o[3];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+
+    float kv[12], vv[3][4];
+    const int ntile = (len + 15) >> 4;
+#define EV_ATT_LOAD(KT)                                                                                        \
+    {                                                                                                          \
+        const int kr_ = min((KT) * 16 + fr, len - 1);                                                          \
+        const float4* kp_ = reinterpret_cast<const float4*>(base + (row0 + kr_) * p.ld + p.C + h * DK + g * 12); \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) { const float4 t = kp_[c]; kv[4 * c] = t.x; kv[4 * c + 1] = t.y; kv[4 * c + 2] = t.z; kv[4 * c + 3] = t.w; } \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+            const float* vp_ = base + (row0 + min((KT) * 16 + 4 * g + i, len - 1)) * p.ld + 2 * p.C + h * DK + fr; \
+            _Pragma("unroll") for (int dt = 0; dt < 3; ++dt) vv[dt][i] = vp_[dt * 16];                          \
+        }                                                                                                      \
+    }
+    EV_ATT_LOAD(0)
+    for (int kt = 0; kt < ntile; ++kt) {
+        // S^T tile
+        f4 st = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j], qv[j], st, 0, 0, 0);
+        float vcur[3][4];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vcur[dt][i] = vv[dt][i];
+        if (kt + 1 < ntile) EV_ATT_LOAD(kt + 1)          // next tile's K / V rows arrive under this tile's softmax and PV
+        // mask keys beyond the utterance, online softmax over the 16 keys of this tile (4 per lane x 4 lane groups)
+        float sc[4];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = (kt * 16 + 4 * g + i < len) ? st[i] : -INFINITY;
+            cm = fmaxf(cm, sc[i]);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 16));
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float alpha = expf(m - mn);            // m = -inf on the first tile -> 0
+        m = mn;
+        float pr[4];
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pr[i] = expf(sc[i] - mn); ps += pr[i]; }
+        l = l * alpha + ps;                          // per-lane partial row sum; the 4 lane groups are added at the end
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            o[dt] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vcur[dt][i], pr[i], o[dt], 0, 0, 0);
+        }
+    }
+#undef EV_ATT_LOAD
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (q0 + fr < len) {
+        const float inv = 1.0f / l;
+        float* op = reinterpret_cast<float*>(p.out) + (row0 + q0 + fr) * p.ldo + h * DK + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+            *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+}
+
 void launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.dtype == DT_F16) {
         static const bool valu = getenv("EV_ATTN_VALU") != nullptr;     // A/B switch: fp32-math VALU kernel on fp16 inputs
@@ -406,6 +502,11 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
         }
         hipLaunchKernelGGL((attention_kernel<_Float16, 48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(64), 0, s, p);
     } else {
+        static const bool valu32 = getenv("EV_ATTN_VALU") != nullptr;   // A/B switch: the one-query-per-lane VALU kernel
+        if (!valu32 && p.C / p.heads == 48) {
+            hipLaunchKernelGGL((attention_mfma_f32_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+            return;
+        }
         hipLaunchKernelGGL((attention_kernel<float, 48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(64), 0, s, p);
     }
 }
