@@ -337,7 +337,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += bias2[j];
             if constexpr (EPI & EPI_RARE_ACT) {
-                if (act == ACT_GELU) {
+                if (act == ACT_GELU && (EPI & EPI_O16)) {          // the A&S erf only where the result is rounded to fp16
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j][0] = gelu_fast(v[j][0]); v[j][1] = gelu_fast(v[j][1]); }
                 } else {
@@ -678,7 +678,7 @@ static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
 // token-rate taps to 1e-4 and the durations bit-exact) at ~4x the speed.  The 2^11 scaling keeps the low parts out of fp16's
 // subnormal range.  Activations are split while staging (fp32 global -> two fp16 LDS slabs).
 // Tile 128 x 64, 4 waves (64 x 32 per wave), one K step = 32 elements, register prefetch of the next step's tiles.
-template <int BM, int BN>
+template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmParams p) {
     constexpr int TT = 64, TC = BN / 2, MT = 4, NT = TC / 16;
     constexpr int SLAB = BM + MAX_SPAN, XCH = SLAB * 4 / 256, WCH = BN * 4 / 256;
@@ -821,16 +821,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] += accl[a][b] * (1.0f / 2048.0f);
+#ifdef EV_TRACE
     gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+#else
+    if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+    else gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+#endif
 }
 
-static void launch_split(const ConvGemmParams& p, hipStream_t s) {
+template <int EPI>
+static void launch_split_epi(const ConvGemmParams& p, hipStream_t s) {
     constexpr int BM = 128, BN = 64;
     const size_t lds = 4 * (size_t)(BM + MAX_SPAN) * 64 + 4 * (size_t)BN * 64;
     static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
     const int grid = (p.M / BM) * (p.N / BN);
-    hipLaunchKernelGGL((conv_gemm_split_kernel<BM, BN>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_gemm_split_kernel<BM, BN, EPI>), dim3(grid), dim3(256), lds, s, p);
+}
+
+static void launch_split(const ConvGemmParams& p, hipStream_t s) {
+    // the token-rate GEMMs write fp32 only: plain / fp32 residual / relu-gelu (exact erff: fp32 output) use the straight-line
+    // epilogue, the per-utterance bias of embed_projection1 (and anything else) the generic one
+    const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
+    const bool o32 = p.out32 && !p.out16 && !p.out32_before_post && !p.post_lrelu;
+    const bool plain = !p.seq_bias && !p.acc32 && !p.add16_a && o32 && p.act != ACT_LRELU && !getenv("EV_EPI_GENERIC");
+    if (plain && !p.res && !rare_act) return launch_split_epi<EPI_O32>(p, s);
+    if (plain && !p.res && rare_act) return launch_split_epi<EPI_RARE_ACT | EPI_O32>(p, s);
+    if (plain && p.res && p.res_dtype == DT_F32 && !rare_act) return launch_split_epi<EPI_RES32 | EPI_O32>(p, s);
+    launch_split_epi<EPI_GENERIC>(p, s);
 }
 
 // =====================================================================================================================
