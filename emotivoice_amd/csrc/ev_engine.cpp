@@ -383,7 +383,9 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
 }
 
 // Variance / duration predictor (reference modules/variance.py:36-56, 101-124): n x [conv k3 -> ReLU -> LN] -> Linear(C,1)
-int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, const Buf& xin, Buf& t1, Buf& t2, float* out_rows) {
+int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, const Buf& xin, Buf& t1, Buf& t2, float* out_rows,
+                  hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     const int C = h->cfg.hidden, k = h->cfg.var_kernel;
     const std::string sp(name);
     const void* cur = xin.p;
@@ -395,7 +397,7 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
         p.dtype = DT_F32; p.A = cur; p.lda = C; p.W = w; p.bias = b; p.M = rc.R; p.N = C; p.K = C; p.taps = k; p.center = (k - 1) / 2;
         p.row_valid = rc.valid; p.act = ACT_RELU; p.out32 = (float*)t1.p; p.ldo = C;
         if (tok_weights(h, lp + ".conv.w", p)) return -1;
-        if (gemm(h, "variance_f32_gemm", p, rc.n_valid)) return -1;
+        if (gemm(h, "variance_f32_gemm", p, rc.n_valid, st)) return -1;
         LayerNormParams ln{};
         ln.x = (const float*)t1.p; ln.ldx = C; ln.rows = rc.R; ln.C = C; ln.gamma = g; ln.beta = be; ln.eps = 1e-12f;
         ln.row_valid = rc.valid; ln.ldo = C;
@@ -407,7 +409,7 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
             if (get_scalar(h, sp + ".lin.b", &lbv)) return -1;
             ln.dot_w = lw; ln.dot_b = lbv; ln.dot_out = out_rows;
         }
-        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 8.0); launch_layernorm(ln, h->stream); }
+        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 8.0, st); launch_layernorm(ln, st); }
         cur = t2.p;
     }
     return 0;
@@ -901,7 +903,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
 
     // ---------------- phase 1: token-rate arena
     struct TokBufs {
-        Buf x, hb, qkv, ctx, ffn, y, xp, xvar, t1, t2, pitch, energy, logd, centre;
+        Buf x, hb, qkv, ctx, ffn, y, xp, xvar, t1, t2, t1b, t2b, t1c, t2c, pitch, energy, logd, centre;
         std::vector<Buf> ltaps; Buf tokemb_tap;
         int64_t* d_ling; int64_t* d_spk; float* d_style; float* d_content; float* d_u;
         int64_t* d_dur; float* d_logd_packed; float* d_pitch_packed; float* d_energy_packed; int64_t* d_forced; int64_t* d_scr;
@@ -920,6 +922,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         tb.x = ap.rows(Rt, C, 4); tb.hb = ap.rows(Rt, C, 4); tb.qkv = ap.rows(Rt, 3 * C, 4); tb.ctx = ap.rows(Rt, C, 4);
         tb.ffn = ap.rows(Rt, 4 * C, 4); tb.y = ap.rows(Rt, C, 4); tb.xp = ap.rows(Rt, C, 4); tb.xvar = ap.rows(Rt, C, 4);
         tb.t1 = ap.rows(Rt, C, 4); tb.t2 = ap.rows(Rt, C, 4);
+        tb.t1b = ap.rows(Rt, C, 4); tb.t2b = ap.rows(Rt, C, 4); tb.t1c = ap.rows(Rt, C, 4); tb.t2c = ap.rows(Rt, C, 4);
         tb.pitch = ap.rows(Rt, 1, 4); tb.energy = ap.rows(Rt, 1, 4); tb.logd = ap.rows(Rt, 1, 4); tb.centre = ap.rows(Rt, 1, 4);
         if (keep) { tb.ltaps.resize(c.enc_layers); for (auto& b : tb.ltaps) b = ap.rows(Rt, C, 4); tb.tokemb_tap = ap.rows(Rt, C, 4); }
         tok_arena_end = ap.off;
@@ -971,9 +974,21 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         if (tok_weights(h, "proj.w", p)) return -1;
         if (gemm(h, "variance_f32_gemm", p, NT)) return -1;
     }
-    if (run_predictor(h, "pitch", c.pitch_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.pitch.p)) return -1;
-    if (run_predictor(h, "energy", c.energy_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.energy.p)) return -1;
-    if (run_predictor(h, "dur", c.dur_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.logd.p)) return -1;
+    {
+        // the three predictors only share their input: pitch and energy run on the auxiliary streams beside the duration
+        // predictor (each conv is one partial wave of 396 workgroups on 256 CUs)
+        const bool conc = !h->profiling && c.vocoder_streams != 1 && h->aux[0] && h->aux[1];
+        if (conc) {
+            (void)hipEventRecord(h->ev_fork, h->stream);
+            (void)hipStreamWaitEvent(h->aux[0], h->ev_fork, 0);
+            (void)hipStreamWaitEvent(h->aux[1], h->ev_fork, 0);
+        }
+        if (run_predictor(h, "pitch", c.pitch_layers, trc, tb.xp, tb.t1b, tb.t2b, (float*)tb.pitch.p, conc ? h->aux[0] : nullptr)) return -1;
+        if (run_predictor(h, "energy", c.energy_layers, trc, tb.xp, tb.t1c, tb.t2c, (float*)tb.energy.p, conc ? h->aux[1] : nullptr)) return -1;
+        if (conc) { (void)hipEventRecord(h->ev_join[0], h->aux[0]); (void)hipEventRecord(h->ev_join[1], h->aux[1]); }
+        if (run_predictor(h, "dur", c.dur_layers, trc, tb.xp, tb.t1, tb.t2, (float*)tb.logd.p)) return -1;
+        if (conc) { (void)hipStreamWaitEvent(h->stream, h->ev_join[0], 0); (void)hipStreamWaitEvent(h->stream, h->ev_join[1], 0); }
+    }
     {
         WPTR(wp, float, "pitch_emb.w"); WPTR(bp, float, "pitch_emb.b"); WPTR(we, float, "energy_emb.w"); WPTR(be, float, "energy_emb.b");
         KScope ks(h, "var_embed_add", 0, (double)NT * C * 8.0);

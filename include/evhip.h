@@ -71,7 +71,8 @@ typedef struct ev_config {
                                    value; measured slower than whole tensors in the full forward, hence off); 0 (default): whole
                                    tensors */
     int32_t vocoder_streams;    /* 0 (default): the three ResBlocks of a generator stage run concurrently (two internal streams beside
-                                   the handle's); 1: everything on the handle's stream */
+                                   the handle's); 1: everything on the handle's stream.  The pitch / energy predictors use the same two streams beside the
+                                   duration predictor. */
     int32_t reserved[5];
 } ev_config;
 
