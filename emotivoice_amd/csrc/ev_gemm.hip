@@ -8,8 +8,12 @@
 // The activation slab [BM + (taps-1)*dil rows][64 bytes of K] is staged ONCE per K-chunk in LDS
 // and re-used by every tap (this is what makes a k=11 dilated conv 11x more arithmetic-intense
 // than a GEMM on an im2col matrix); the weight tile of each (K-chunk, tap) step is double-buffered.
-// Staged rows are 64 B of data + 16 B pad (80 B pitch) so that the 16 rows of a ds_read_b128
-// fragment read hit distinct 16-byte LDS slots.
+// Staged rows are 64 B with an XOR swizzle of the 16-byte parts (see "main kernel" below) so that
+// the 16 rows of a ds_read_b128 fragment read hit distinct LDS slots at any tap offset.
+//
+// File map: generic LDS-transposed epilogue (every operand a run-time flag; fp32 / split kernels' fallback) ->
+// specialised straight-line epilogue (template flags, the frame-rate path) -> main conv-GEMM kernel + launch
+// heuristics -> split-precision kernel (token-rate fp32 path) -> fused ResBlock-pair kernels for C = 32 / C = 64.
 //
 // DT_F16: v_mfma_f32_16x16x32_f16, fp32 accumulate.  DT_F32: v_mfma_f32_16x16x4_f32 (bit-exact
 // fp32 FMA chain) for the duration-critical token-rate path.  Both share the byte geometry:
