@@ -131,8 +131,11 @@ class JETSGeneratorHIP:
         packed = np.ascontiguousarray(np.concatenate([ling[b, :lengths[b]] for b in range(B)]))
         cu = np.zeros(B + 1, np.int32)
         cu[1:] = np.cumsum(lengths)
-        res = eng.synthesize_raw(B, packed.ctypes.data, cu, spk.ctypes.data, style.ctypes.data, content.ctypes.data,
-                                 float(alpha), 0)
+        # alpha: the reference's inference branch calls the length regulator without it (model_open_source.py:142; alpha only
+        # reaches GaussianUpsampling in the teacher-forced branch :138), so any value gives the alpha = 1 result there, and
+        # here.  Speed control is available on the engine (EVEngine.synthesize(alpha=...), ev_synthesize's alpha).
+        del alpha
+        res = eng.synthesize_raw(B, packed.ctypes.data, cu, spk.ctypes.data, style.ctypes.data, content.ctypes.data, 1.0, 0)
         T = np.array([res.mel_lens[b] for b in range(B)], np.int64)
         offs = np.array([res.mel_offsets[b] for b in range(B + 1)], np.int64)
         up = self.upsample_factor

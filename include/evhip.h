@@ -127,7 +127,9 @@ int ev_load_weights_device(ev_handle* h, const void* dptr, size_t nbytes, const 
  *   speaker   (B,) int64                                     = inputs_speaker
  *   style     (B, bert_dim) fp32                             = inputs_style_embedding
  *   content   (B, bert_dim) fp32                             = inputs_content_embedding
- *   alpha     duration scale (reference call sites pass 1.0)
+ *   alpha     duration scale as GaussianUpsampling.forward applies it (alignment.py:183).  NB: the reference's inference branch
+ *             never forwards JETSGenerator.forward's alpha to the length regulator (model_open_source.py:142), so the drop-in
+ *             Python mirror always passes 1.0; values != 1 are an extension (speed control)
  * Every utterance is evaluated with the reference's B = 1 semantics (zero halo at sequence edges,
  * attention restricted to its own tokens / frames). */
 int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu_seqlens,

@@ -119,7 +119,7 @@ def gaussian_upsampling(hs, ds, alpha=1.0, delta=0.1):
     return torch.matmul(p_attn, hs), T_feats                              # :210
 
 
-def am_forward(sd, ling, speaker, style, content, shapes, alpha=1.0, taps=None, durations=None):
+def am_forward(sd, ling, speaker, style, content, shapes, alpha=1.0, taps=None, durations=None, duration_scale=1.0):
     """models/prompt_tts_modified/model_open_source.py:102-147 (mel_targets=None branch).
 
     ling (N,) int64; speaker int; style/content (768,) fp32.  ``durations`` (N,) int64
@@ -149,7 +149,12 @@ def am_forward(sd, ling, speaker, style, content, shapes, alpha=1.0, taps=None, 
     x = x + p_emb + e_emb                                                                        # :134
     if taps is not None:
         taps["x_var"] = x
-    up, T = gaussian_upsampling(x, d_outs, alpha)                                                # :142
+    # :142 -- the inference branch calls ``self.length_regulator(x, d_outs, None, ~src_mask)`` WITHOUT alpha: the ``alpha``
+    # argument of JETSGenerator.forward only reaches GaussianUpsampling in the teacher-forced branch (:138), so it has no
+    # effect here (pinned by tests/golden/n24_alpha1p3.npz, generated by the reference with alpha = 1.3).
+    # ``duration_scale`` is the extension ev_synthesize exposes: GaussianUpsampling.forward's own alpha (alignment.py:183).
+    del alpha
+    up, T = gaussian_upsampling(x, d_outs, duration_scale)
     if taps is not None:
         taps["upsampled"] = up
         taps["mel_len"] = torch.tensor(T)
@@ -214,11 +219,12 @@ def hifigan_forward(sd, mel_ct, shapes, taps=None, prefix="generator"):
 
 
 def jets_forward(sd, ling, speaker, style, content, shapes, alpha=1.0, taps: Optional[dict] = None,
-                 durations=None):
-    """models/prompt_tts_modified/jets.py:50-71, inference branch (:61-66), one utterance."""
+                 durations=None, duration_scale=1.0):
+    """models/prompt_tts_modified/jets.py:50-71, inference branch (:61-66), one utterance.  ``alpha`` is accepted and, like in
+    the reference's inference branch, ignored (see am_forward); ``duration_scale`` is not part of the reference call."""
     with torch.no_grad():
         ling, style, content = _t(ling).long(), _t(style).float(), _t(content).float()
-        out = am_forward(sd, ling, int(speaker), style, content, shapes, alpha, taps, durations)
+        out = am_forward(sd, ling, int(speaker), style, content, shapes, alpha, taps, durations, duration_scale)
         wav = hifigan_forward(sd, out["dec_outputs"].t().contiguous(), shapes, taps)              # :62-66
         if taps is not None:
             taps["wav"] = wav

@@ -9,7 +9,7 @@ For each case the synthetic weights of oracle/weights.py are loaded with
 does (B = 1, keyword args, alpha = 1.0, torch.no_grad), and inputs, outputs and
 stage taps (forward hooks) are written to a small .npz.
 
-Usage:  python tests/golden/make_golden.py            (re-creates every fixture)
+Usage:  python tests/golden/make_golden.py [--only <case>]      (re-creates every fixture, or one)
 """
 import os
 import sys
@@ -46,7 +46,7 @@ def load_reference():
     return JETSGenerator(conf).eval()
 
 
-def run_reference(gen, sd_np, utt):
+def run_reference(gen, sd_np, utt, alpha=1.0):
     gen.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
     taps = {}
 
@@ -75,7 +75,7 @@ def run_reference(gen, sd_np, utt):
                   input_lengths=torch.tensor([ling.shape[1]]),
                   inputs_content_embedding=torch.from_numpy(utt["content"]).unsqueeze(0),
                   inputs_speaker=torch.tensor([utt["speaker"]]),
-                  alpha=1.0)
+                  alpha=alpha)
         log_d = am.duration_predictor(taps["x_proj"].unsqueeze(0), None).squeeze(0)
     for h in hs:
         h.remove()
@@ -98,6 +98,8 @@ CASES = {
     "tiny_parity": (0, "parity", 11, [12], [5]),
     "n40_stress": (0, "stress", 12, [40], [1999]),
     "n33_bench": (0, "bench", 13, [33], [0]),
+    # speed control (alpha scales the float durations before the cumsum, alignment.py:185; mel_len = int(sum))
+    "n24_alpha1p3": (0, "stress", 15, [24], [77], 1.3),
 }
 
 
@@ -136,17 +138,26 @@ def main():
     gen = load_reference()
     shapes = EVShapes()
     sds = {}
-    for name, (wseed, mode, iseed, lengths, speakers) in CASES.items():
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    for name, case in CASES.items():
+        if only and name != only:
+            continue
+        wseed, mode, iseed, lengths, speakers = case[:5]
+        alpha = case[5] if len(case) > 5 else 1.0
         if (wseed, mode) not in sds:
             sds[(wseed, mode)] = synth_state_dict(wseed, mode, shapes)
         utt = synth_inputs(iseed, lengths, speakers, shapes)[0]
-        res = run_reference(gen, sds[(wseed, mode)], utt)
+        res = run_reference(gen, sds[(wseed, mode)], utt, alpha)
         res = subsample_taps(res)
+        if alpha != 1.0:
+            res["alpha"] = np.float32(alpha)
         res.update(in_ling=utt["ling"], in_speaker=np.int64(utt["speaker"]), in_style=utt["style"],
                    in_content=utt["content"], weight_seed=np.int64(wseed), dur_mode=np.array(mode))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
         print(name, "N", lengths[0], "T", int(res["mel_len"]), "dur[min,max]", res["dur"].min(), res["dur"].max(),
               "wav rms %.4f" % float(np.sqrt((res["wav"] ** 2).mean())))
+    if only and only != "real_line1":
+        return
     utt, line = real_line_case()
     if (0, "parity") not in sds:
         sds[(0, "parity")] = synth_state_dict(0, "parity", shapes)

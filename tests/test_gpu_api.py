@@ -27,11 +27,13 @@ def ctx():
 
 
 def test_alpha_scales_durations_like_the_reference(ctx):
-    """alignment.py:183: ds = ds * alpha (float), T = int(sum), centres from the scaled durations."""
+    """ev_synthesize's alpha is GaussianUpsampling.forward's own alpha (alignment.py:183: ds = ds * alpha (float), T = int(sum),
+    centres from the scaled durations).  The reference's inference branch never forwards JETSGenerator.forward's alpha to it
+    (model_open_source.py:142), so this is an extension of the C ABI; the Python mirror passes 1.0 (test_gpu_generator.py)."""
     from oracle import EVShapes, jets_forward
     u = ctx["utts"][0]
     for alpha in (1.3, 0.6):
-        ref = jets_forward(ctx["sd"], u["ling"], u["speaker"], u["style"], u["content"], EVShapes(), alpha=alpha)
+        ref = jets_forward(ctx["sd"], u["ling"], u["speaker"], u["style"], u["content"], EVShapes(), duration_scale=alpha)
         out = ctx["eng"].synthesize([u], alpha=alpha, vocoder=False)
         assert np.array_equal(out["durations"], ref["log_duration_predictions"].numpy())     # unscaled integer durations
         assert int(out["mel_lens"][0]) == int(ref["mel_len"])

@@ -24,7 +24,7 @@ def _sd(seed, mode):
 
 
 def test_fixtures_present():
-    assert len(CASES) >= 4
+    assert len(CASES) >= 5
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
@@ -32,7 +32,8 @@ def test_oracle_matches_reference(path):
     g = np.load(path)
     sd = _sd(int(g["weight_seed"]), str(g["dur_mode"]))
     taps = {}
-    out = jets_forward(sd, g["in_ling"], int(g["in_speaker"]), g["in_style"], g["in_content"], EVShapes(), taps=taps)
+    alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
+    out = jets_forward(sd, g["in_ling"], int(g["in_speaker"]), g["in_style"], g["in_content"], EVShapes(), alpha=alpha, taps=taps)
     # integer path: bit exact
     assert np.array_equal(out["log_duration_predictions"].numpy(), g["dur"])
     assert int(out["mel_len"]) == int(g["mel_len"])
