@@ -64,6 +64,19 @@ def test_oracle_matches_reference(path):
     assert n_taps >= 15
 
 
+def test_alpha_is_ignored_but_duration_scale_is_not():
+    """model_open_source.py:142 drops alpha in the inference branch; the oracle's duration_scale is GaussianUpsampling's own
+    alpha (alignment.py:183-195: float scaling, mel_len = int(sum))."""
+    g = np.load(os.path.join(GOLDEN_DIR, "tiny_parity.npz"))
+    sd = _sd(int(g["weight_seed"]), str(g["dur_mode"]))
+    args = (sd, g["in_ling"], int(g["in_speaker"]), g["in_style"], g["in_content"], EVShapes())
+    a = jets_forward(*args, alpha=0.5)
+    assert int(a["mel_len"]) == int(g["mel_len"]) and rel_l2(a["dec_outputs"].numpy(), g["mel"]) < 2e-5
+    b = jets_forward(*args, duration_scale=1.3)
+    assert int(b["mel_len"]) == int(np.float32(g["dur"].astype(np.float32) * np.float32(1.3)).sum().astype(np.int32))
+    assert np.array_equal(b["log_duration_predictions"].numpy(), g["dur"])
+
+
 def test_int16_epilogue_truncates_toward_zero():
     # inference_am_vocoder_joint.py:130-131: numpy astype('int16') == C cast
     x = np.array([0.0, 0.99997, -0.99997, 1.5 / 32768, -1.5 / 32768, 0.5], np.float32)
