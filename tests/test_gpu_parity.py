@@ -189,6 +189,22 @@ def test_batch_invariance_bit_exact(gpu):
         assert np.array_equal(solo["wav"], wavs[b]), b
 
 
+def test_shortest_utterances(gpu):
+    """1-, 2- and 3-phoneme utterances (fewer rows than any conv's taps, one attention key) inside a batch, against the
+    oracle (which matches the reference on exactly these inputs: 0 mel difference on CPU)."""
+    from oracle import synth_inputs
+    eng = _engine("parity", "f16")
+    utts = [synth_inputs(30 + n, [n], [n])[0] for n in (1, 2, 3)] + synth_inputs(34, [17], [9])
+    out = eng.synthesize(utts)
+    cu = out["cu_seqlens"]
+    for b, u in enumerate(utts):
+        ref = _oracle("parity", u)
+        assert np.array_equal(out["durations"][cu[b]:cu[b + 1]], ref["log_duration_predictions"].numpy()), b
+        assert int(out["mel_lens"][b]) == int(ref["mel_len"])
+        assert rel_l2(out["mel_list"][b], ref["dec_outputs"].numpy()) < TOL_OUT, b
+        assert rel_l2(out["wav_list"][b], ref["wav_predictions"].numpy()) < TOL_OUT, b
+
+
 def test_forced_durations_and_zero_duration_guard(gpu):
     """Teacher-forced durations incl. zeros, and the all-zero guard of alignment.py:187-191."""
     from oracle import synth_inputs
