@@ -68,7 +68,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--phonemes", type=int, default=256)
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances for the CPU baseline sample (0 = skip)")
-    ap.add_argument("--decoder-precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--precision", default="fast", choices=["fast", "strict"],
+                    help="frame-rate path: fast = fp16 MFMA operands (BASELINE configs[1]/[4]: bf16 / fp16); strict = split precision "
+                         "(3 fp16 MFMAs per product, fp32 activations)")
+    ap.add_argument("--decoder-precision", default=None, choices=["f16", "f32", "x3"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: put every rank on this device (with --backend gloo)")
     args = ap.parse_args()
@@ -99,7 +102,7 @@ def main():
 
     # weights: rank 0 packs, everyone receives the blob with one broadcast (RCCL over xGMI), borrowed in place
     blob_t = broadcast_blob(rank, world, local_rank, dist, dur_mode="bench")
-    eng = EVEngine(device_id=local_rank, decoder_precision=args.decoder_precision,
+    eng = EVEngine(device_id=local_rank, precision=args.precision, decoder_precision=args.decoder_precision,
                    vocoder_chunk_mb=int(os.environ.get("EV_CHUNK_MB", "0")),       # tuning overrides; 0 = engine default
                    vocoder_streams=int(os.environ.get("EV_VOC_STREAMS", "0")))
     eng.load_blob_device(blob_t.data_ptr(), blob_t.numel(), keepalive=blob_t)
@@ -150,7 +153,7 @@ def main():
         stages = eng.timings()
         eng.set_profiling(False)
         f1 = int(res.total_frames)
-        voc = stats.get("voc_conv_gemm_f16")
+        voc = stats.get("voc_conv_gemm_f16") or stats.get("voc_conv_gemm_x3")
         traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
         tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
         if os.path.exists(tpath) and B == 32 and N == 256:
@@ -214,11 +217,13 @@ def main():
         "x_realtime": round(value * hop / sr, 1),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if args.decoder_precision == "f16" else "f32-decoder/f16-vocoder", "data": "synthetic",
+        "dtype": "f16" if (eng.decoder_precision, eng.vocoder_precision) == ("f16", "f16") else
+                 "decoder %s / vocoder %s (x3 = fp16 hi/lo split, 3 MFMAs per product, fp32 activations)" % (eng.decoder_precision, eng.vocoder_precision),
+        "data": "synthetic",
         "config": {"workload": "configs[1]: batch=%d x %d-phoneme synthetic utterances per GPU, 1 speaker, AM+vocoder end-to-end, "
                                "4 frames/phoneme" % (B, N), "global_batch": B * world, "phonemes": N,
                    "frames_per_utt": int(frames / args.steps / world / B), "parallelism": "utterance-sharded x%d" % world,
-                   "token_rate_precision": "f32", "frame_rate_precision": args.decoder_precision},
+                   "token_rate_precision": "f32", "frame_rate_precision": "%s/%s" % (eng.decoder_precision, eng.vocoder_precision)},
         "latency": lat, "roofline": roof, "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "kernels_ms": kernels,
     }
     if world == 1 and args.cpu_utts > 0:

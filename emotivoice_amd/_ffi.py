@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVHIP_LIB", os.path.join(_HERE, "csrc", "libevhip.so"))
 EV_ABI_VERSION = 1
-EV_PREC_F16, EV_PREC_F32 = 0, 1
+EV_PREC_F16, EV_PREC_F32, EV_PREC_X3 = 0, 1, 2
 EV_FLAG_DEVICE_INPUTS, EV_FLAG_NO_VOCODER, EV_FLAG_WANT_INT16, EV_FLAG_FORCED_DURATIONS = 1, 2, 4, 8
 
 
@@ -25,7 +25,8 @@ class ev_config(C.Structure):
         ("up_rates", C.c_int32 * 8), ("up_kernels", C.c_int32 * 8), ("up_init_ch", C.c_int32), ("n_rb", C.c_int32),
         ("rb_kernels", C.c_int32 * 8), ("rb_dils", (C.c_int32 * 4) * 8), ("n_rb_dils", C.c_int32),
         ("sample_rate", C.c_int32), ("decoder_precision", C.c_int32), ("keep_stages", C.c_int32),
-        ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("vocoder_streams", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("vocoder_streams", C.c_int32),
+        ("vocoder_precision", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 

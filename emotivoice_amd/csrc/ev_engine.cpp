@@ -276,7 +276,8 @@ void profiling_collect(ev_handle* h) {
 int check_gemm(ev_handle* h, const ConvGemmParams& p) {
     const int es = p.dtype == DT_F16 ? 2 : 4;
     if (p.M % ROW_ALIGN) return fail(h, "gemm: M=%d not a multiple of %d", p.M, ROW_ALIGN);
-    if (p.dtype == DT_F32S && (p.K % 32 || p.N % 64 || !p.W_lo || p.pro_lrelu)) return fail(h, "gemm: bad split-precision call");
+    if (p.dtype == DT_F32S && (p.K % 32 || !p.W_lo)) return fail(h, "gemm: bad split-precision call");
+    if (p.pro_lrelu && !(p.pro_slope >= 0.f && p.pro_slope <= 1.f)) return fail(h, "gemm: prologue leaky-relu slope %g outside [0, 1]", p.pro_slope);
     if (p.N % 32) return fail(h, "gemm: N=%d not a multiple of 32", p.N);
     if ((p.K * es) % 64) return fail(h, "gemm: K=%d not a multiple of %d", p.K, 64 / es);
     if ((p.taps - 1) * p.dil > 64) return fail(h, "gemm: conv span %d > 64", (p.taps - 1) * p.dil);
@@ -304,8 +305,10 @@ ConvGemmParams gemm_defaults() {
 
 // token-rate (fp32) GEMM operands: exact fp32 MFMA or the hi/lo split pair (cfg.token_rate_split)
 int tok_weights(ev_handle* h, const std::string& base /* e.g. "enc.0.qkv.w" */, ConvGemmParams& p) {
-    if (h->cfg.token_rate_split && base.compare(0, 4, "dec.") != 0) {
-        const WeightEntry* hi = W(h, base + "32h");
+    const bool dec = base.compare(0, 4, "dec.") == 0 || base.compare(0, 7, "to_mel.") == 0;
+    if (dec ? h->cfg.decoder_precision == EV_PREC_X3 : h->cfg.token_rate_split != 0) {
+        // hi part: fp16(w).  The token-rate stack packs it as "<name>32h"; for the decoder it is the fp16 copy "<name>16"
+        const WeightEntry* hi = W(h, base + (h->wt.count(base + "32h") ? "32h" : "16"));
         const WeightEntry* lo = W(h, base + "32l");
         if (!hi || !lo) return -1;
         p.dtype = DT_F32S; p.W = hi->ptr; p.W_lo = lo->ptr;
@@ -386,12 +389,16 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
 int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, const Buf& xin, Buf& t1, Buf& t2, float* out_rows,
                   hipStream_t st = nullptr) {
     if (!st) st = h->stream;
-    const int C = h->cfg.hidden, k = h->cfg.var_kernel;
+    const int C = h->cfg.hidden;
     const std::string sp(name);
     const void* cur = xin.p;
     for (int i = 0; i < layers; ++i) {
         const std::string lp = sp + "." + std::to_string(i);
         WPTR(w, char, lp + ".conv.w32"); WPTR(b, float, lp + ".conv.b");
+        // kernel size = the packed weight's tap dimension ([C][k][C]): duration / pitch / energy predictors have their own sizes in
+        // the reference (model_open_source.py:46-76: duration_kernel_size, variance_kernel_size, energy hard-coded to 3)
+        const int k = (int)W(h, lp + ".conv.w32")->dims[1];
+        if ((k - 1) / 2 > GAP) return fail(h, "%s: kernel %d needs a halo of %d rows > the %d gap rows between utterances", lp.c_str(), k, (k - 1) / 2, GAP);
         WPTR(g, float, lp + ".ln.g"); WPTR(be, float, lp + ".ln.b");
         ConvGemmParams p = gemm_defaults();
         p.dtype = DT_F32; p.A = cur; p.lda = C; p.W = w; p.bias = b; p.M = rc.R; p.N = C; p.K = C; p.taps = k; p.center = (k - 1) / 2;
@@ -417,30 +424,56 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
 
 struct VocBufs { Buf pre, xu[4], tmp[3], rba[3], rbb[3], nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap; };
 
-// HiFi-GAN generator (reference models/hifigan/models.py:115-131) on channels-last fp16 rows.
-int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs& vb, bool keep) {
+// weights of one generator conv: fp16 (also the "hi" part of the split) and, in the split-precision mode, the "lo" part
+int voc_weights(ev_handle* h, const std::string& base /* e.g. "voc.rb3.c1.0" */, bool x3, ConvGemmParams& p) {
+    const WeightEntry* w = W(h, base + ".w16");
+    const WeightEntry* b = W(h, base + ".b");
+    if (!w || !b) return -1;
+    p.W = w->ptr; p.bias = reinterpret_cast<const float*>(b->ptr);
+    if (x3) {
+        const WeightEntry* lo = W(h, base + ".w16l");
+        if (!lo) return -1;
+        p.dtype = DT_F32S; p.W_lo = lo->ptr;
+    } else {
+        p.dtype = DT_F16; p.W_lo = nullptr;
+    }
+    return 0;
+}
+
+// HiFi-GAN generator (reference models/hifigan/models.py:115-131) on channels-last rows.
+// vocoder_precision F16: fp16 activations, every leaky-relu fused into the producer (post_lrelu) or the consumer's staging.
+// vocoder_precision X3:  fp32 activations, split-precision products; every stored tensor is the RAW module output of the
+// reference (so the Appendix-C taps are the buffers themselves) and each consumer applies its leaky-relu while staging.
+int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs& vb, bool keep) {
     const ev_config& c = h->cfg;
-    WPTR(wpre, char, "voc.pre.w16"); WPTR(bpre, float, "voc.pre.b");
+    const bool x3 = c.vocoder_precision == EV_PREC_X3;
+    const size_t ves = x3 ? 4 : 2;
+    auto set_out = [&](ConvGemmParams& q, void* dst) { if (x3) q.out32 = (float*)dst; else q.out16 = dst; };
     ConvGemmParams p = gemm_defaults();
-    p.dtype = DT_F16; p.A = mel16.p; p.lda = MEL_PAD; p.W = wpre; p.bias = bpre; p.M = Rf; p.N = c.up_init_ch; p.K = MEL_PAD;
-    p.taps = 7; p.center = 3; p.row_valid = h->d_frm_valid; p.valid_shift = 0;
-    p.post_lrelu = 1; p.post_slope = 0.1f;      // leaky_relu(0.1) of models.py:118 fused into the producer
-    p.out16 = vb.pre.p; p.ldo = c.up_init_ch;
-    if (keep) { p.out32 = (float*)vb.pre_tap.p; p.out32_before_post = 1; }
-    if (gemm(h, "voc_conv_gemm_f16", p, n_frames)) return -1;
+    if (voc_weights(h, "voc.pre", x3, p)) return -1;
+    p.A = melin.p; p.lda = MEL_PAD; p.M = Rf; p.N = c.up_init_ch; p.K = MEL_PAD;
+    p.taps = 7; p.center = 3; p.row_valid = h->d_frm_valid; p.valid_shift = 0; p.ldo = c.up_init_ch;
+    set_out(p, vb.pre.p);
+    if (!x3) {
+        p.post_lrelu = 1; p.post_slope = 0.1f;      // leaky_relu(0.1) of models.py:118 fused into the producer
+        if (keep) { p.out32 = (float*)vb.pre_tap.p; p.out32_before_post = 1; }
+    }
+    if (gemm(h, x3 ? "voc_conv_gemm_x3" : "voc_conv_gemm_f16", p, n_frames)) return -1;
+    const char* gname = x3 ? "voc_conv_gemm_x3" : "voc_conv_gemm_f16";
     const void* prev = vb.pre.p;
     int ch = c.up_init_ch, U = 1;
     for (int i = 0; i < c.n_up; ++i) {
         const int s = c.up_rates[i], cout = ch / 2;
         const int rows_in = Rf * U, rows_out = rows_in * s;
         const double valid_in = n_frames * U, valid_out = valid_in * s;
-        const std::string up = "voc.up" + std::to_string(i);
-        WPTR(wu, char, up + ".w16"); WPTR(bu, float, up + ".b");
         // ConvTranspose1d(k = 2s, pad = s/2) == 3-tap conv with N = s * C_out, viewed as [rows_in*s][C_out] (models.py:119)
         p = gemm_defaults();
-        p.dtype = DT_F16; p.A = prev; p.lda = ch; p.W = wu; p.bias = bu; p.M = rows_in; p.N = s * cout; p.K = ch; p.taps = 3; p.center = 1;
-        p.row_valid = h->d_frm_valid; p.valid_shift = ilog2(U); p.out16 = vb.xu[i].p; p.ldo = s * cout;
-        if (gemm(h, "voc_conv_gemm_f16", p, valid_in)) return -1;
+        if (voc_weights(h, "voc.up" + std::to_string(i), x3, p)) return -1;
+        p.A = prev; p.lda = ch; p.M = rows_in; p.N = s * cout; p.K = ch; p.taps = 3; p.center = 1;
+        p.row_valid = h->d_frm_valid; p.valid_shift = ilog2(U); p.ldo = s * cout;
+        if (x3) { p.pro_lrelu = 1; p.pro_slope = 0.1f; }          // models.py:118 (the fp16 path has it in the producer's epilogue)
+        set_out(p, vb.xu[i].p);
+        if (gemm(h, gname, p, valid_in)) return -1;
         U *= s;
         const int shift = ilog2(U);
         const bool last_stage = (i == c.n_up - 1);
@@ -455,7 +488,7 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
         // rows that were recomputed from valid inputs inside this chunk; what the extensions write outside [a, b) is dead or
         // rewritten by the neighbouring chunk.
         int nchunks = 1;
-        if (!keep && c.vocoder_chunk_mb > 0) {
+        if (!keep && !x3 && c.vocoder_chunk_mb > 0) {
             const double tensor_mb = (double)rows_out * cout * 2.0 / 1e6;
             nchunks = (int)(tensor_mb / c.vocoder_chunk_mb + 0.5);
             if (nchunks < 1) nchunks = 1;
@@ -464,8 +497,7 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
         const int chunk_rows = ((rows_out + nchunks - 1) / nchunks + 255) / 256 * 256;
         // shift every row-indexed operand of a conv call to the row range [lo, hi)
         auto sub = [&](ConvGemmParams q, int lo, int hi) {
-            const size_t es = 2;     // all frame-rate activations of the vocoder are fp16
-            q.A = (const char*)q.A + (size_t)lo * q.lda * es;
+            q.A = (const char*)q.A + (size_t)lo * q.lda * ves;
             if (q.res) q.res = (const char*)q.res + (size_t)lo * q.ldres * (q.res_dtype == DT_F16 ? 2 : 4);
             if (q.acc32) q.acc32 = q.acc32 + (size_t)lo * q.ldacc;
             if (q.add16_a) { q.add16_a = (const char*)q.add16_a + (size_t)lo * q.ldadd * 2; q.add16_b = (const char*)q.add16_b + (size_t)lo * q.ldadd * 2; }
@@ -478,8 +510,9 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
         // The three ResBlocks of a stage only share the stage input and meet again in the MRF sum: the first two run on
         // auxiliary streams beside the third (its last conv waits for both).  A k = 3 chain is HBM-bound and a k = 11 chain
         // MFMA-bound, so their workgroups complement each other on a CU and fill each other's launch tails.  Profiled steps
-        // (per-launch events) and chunked execution stay on one stream.
-        const bool conc = c.n_rb == 3 && nchunks == 1 && !h->profiling && c.vocoder_streams != 1 && h->aux[0] && h->aux[1];
+        // (per-launch events) and chunked execution stay on one stream.  (Split-precision mode: the MRF sum is a running fp32
+        // accumulator shared by the three ResBlocks, so they run in order on the handle's stream.)
+        const bool conc = c.n_rb == 3 && nchunks == 1 && !x3 && !h->profiling && c.vocoder_streams != 1 && h->aux[0] && h->aux[1];
         if (conc) {
             (void)hipEventRecord(h->ev_fork, h->stream);
             (void)hipStreamWaitEvent(h->aux[0], h->ev_fork, 0);
@@ -496,41 +529,46 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
             hipStream_t sj = (conc && j < 2) ? h->aux[j] : h->stream;
             for (int d = 0; d < c.n_rb_dils; ++d) {
                 const int dil = c.rb_dils[j][d];
-                WPTR(w1, char, rb + ".c1." + std::to_string(d) + ".w16"); WPTR(b1, float, rb + ".c1." + std::to_string(d) + ".b");
-                WPTR(w2, char, rb + ".c2." + std::to_string(d) + ".w16"); WPTR(b2, float, rb + ".c2." + std::to_string(d) + ".b");
-                // fused pair kernels: C = 32 (every k) and C = 64 with k = 3 (the HBM-bound end of the generator)
-                const bool fused = ((cout == 32 && (k == 3 || k == 7 || k == 11)) || (cout == 64 && k == 3)) && !getenv("EV_NO_FUSED_PAIR");
+                const std::string c1 = rb + ".c1." + std::to_string(d), c2 = rb + ".c2." + std::to_string(d);
+                // fused pair kernels: C = 32 (every k) and C = 64 with k = 3 (the HBM-bound end of the generator; fp16 mode only)
+                const bool fused = !x3 && ((cout == 32 && (k == 3 || k == 7 || k == 11)) || (cout == 64 && k == 3)) && !getenv("EV_NO_FUSED_PAIR");
                 if (!fused) {
                     // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
                     p = gemm_defaults();
-                    p.dtype = DT_F16; p.A = xcur; p.lda = cout; p.W = w1; p.bias = b1; p.M = rows_out; p.N = cout; p.K = cout;
+                    if (voc_weights(h, c1, x3, p)) return -1;
+                    p.A = xcur; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
                     p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
-                    p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.out16 = vb.tmp[bj].p; p.ldo = cout;
+                    p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.ldo = cout;
+                    set_out(p, vb.tmp[bj].p);
                     const int e1 = (2 * (c.n_rb_dils - 1 - d) + 1) * 256, lo1 = std::max(0, a0 - e1), hi1 = std::min(rows_out, b0 + e1);
-                    if (gemm(h, "voc_conv_gemm_f16", sub(p, lo1, hi1), valid_out * frac, sj)) return -1;
+                    if (gemm(h, gname, sub(p, lo1, hi1), valid_out * frac, sj)) return -1;
                 }
                 // x = c2(xt) + x  (models.py:54-56)
                 p = gemm_defaults();
-                p.dtype = DT_F16; p.A = vb.tmp[bj].p; p.lda = cout; p.W = w2; p.bias = b2; p.M = rows_out; p.N = cout; p.K = cout;
+                if (voc_weights(h, c2, x3, p)) return -1;
+                p.A = vb.tmp[bj].p; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
                 p.taps = k; p.dil = 1; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
-                p.res = xcur; p.res_dtype = DT_F16; p.ldres = cout; p.ldo = cout;
+                p.res = xcur; p.res_dtype = x3 ? DT_F32 : DT_F16; p.ldres = cout; p.ldo = cout;
                 if (d + 1 < c.n_rb_dils) {
                     void* dst = (d % 2 == 0) ? vb.rba[bj].p : vb.rbb[bj].p;
-                    p.out16 = dst;
+                    set_out(p, dst);
                     xcur = dst;
                 } else {
                     // MRF: xs += resblock(x); x = xs / num_kernels (models.py:121-126), then the next leaky_relu
-                    // With three ResBlocks (the reference config) the first two scaled branches are kept in fp16 and the third adds
-                    // them in its fp32 epilogue: half the HBM traffic of an fp32 running sum, and the two extra fp16 roundings are of
-                    // the size of the one the stage output gets anyway.  Any other count uses the fp32 accumulator.
+                    // fp16 mode with three ResBlocks (the reference config): the first two scaled branches are kept in fp16 and the
+                    // third adds them in its fp32 epilogue (half the HBM traffic of an fp32 running sum; the two extra fp16
+                    // roundings are of the size of the one the stage output gets anyway).  Any other count, and the
+                    // split-precision mode, use the fp32 running sum.
                     p.out_scale = 1.0f / (float)c.n_rb;
-                    const bool mrf16 = (c.n_rb == 3);
+                    const bool mrf16 = (c.n_rb == 3) && !x3;
                     if (mrf16) {
                         if (j == 2) { p.add16_a = vb.mrf16a.p; p.add16_b = vb.mrf16b.p; p.ldadd = cout; }
                     } else if (j > 0) { p.acc32 = (const float*)vb.mrf32.p; p.ldacc = cout; }
                     if (j + 1 < c.n_rb) {
                         if (mrf16) p.out16 = (j == 0) ? vb.mrf16a.p : vb.mrf16b.p;
                         else p.out32 = (float*)vb.mrf32.p;
+                    } else if (x3) {
+                        p.out32 = (float*)vb.nxt[i].p;               // raw MRF mean (= the voc_mrf tap); consumers apply the leaky-relu
                     } else {
                         p.post_lrelu = 1; p.post_slope = last_stage ? 0.01f : 0.1f;   // models.py:118 / :127
                         p.out16 = vb.nxt[i].p;
@@ -545,14 +583,15 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
                 }
                 if (fused) {
                     // conv1 -> LDS -> conv2 + residual / MRF epilogue in one persistent kernel (ev_gemm.hip)
+                    WPTR(w1, char, c1 + ".w16"); WPTR(b1, float, c1 + ".b");
                     ResPairParams rp;
                     memset(&rp, 0, sizeof rp);
-                    rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = w2; rp.M = p.M; rp.k = k; rp.dil = dil; rp.gmin = -lo2; rp.gmax = rows_out - lo2; rp.epi = p;
+                    rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = p.W; rp.M = p.M; rp.k = k; rp.dil = dil; rp.gmin = -lo2; rp.gmax = rows_out - lo2; rp.epi = p;
                     const double fl = 2.0 * 2.0 * valid_out * frac * cout * (double)cout * k;
                     KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0, sj);
                     if (cout == 32) launch_resblock_pair_c32(rp, sj);
                     else launch_resblock_pair_c64(rp, sj);
-                } else if (gemm(h, "voc_conv_gemm_f16", p, valid_out * frac, sj)) return -1;
+                } else if (gemm(h, gname, p, valid_out * frac, sj)) return -1;
             }
             if (conc && j < 2) (void)hipEventRecord(h->ev_join[j], h->aux[j]);
         }
@@ -564,8 +603,8 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
     float bpv;
     if (get_scalar(h, "voc.post.b", &bpv)) return -1;
     {
-        KScope ks(h, "voc_conv_post", 2.0 * n_frames * U * ch * 7, n_frames * U * (ch * 2.0 + 4.0));
-        launch_conv_post(prev, ch, wpost, bpv, 7, h->d_frm_valid, ilog2(U), (float*)vb.wavrows.p, Rf * U, ch, h->stream);
+        KScope ks(h, "voc_conv_post", 2.0 * n_frames * U * ch * 7, n_frames * U * (ch * (double)ves + 4.0));
+        launch_conv_post(prev, x3 ? 1 : 0, ch, wpost, bpv, 7, x3 ? 0.01f : 1.0f, h->d_frm_valid, ilog2(U), (float*)vb.wavrows.p, Rf * U, ch, h->stream);
     }
     return 0;
 }
@@ -573,8 +612,10 @@ int run_vocoder(ev_handle* h, const Buf& mel16, int Rf, double n_frames, VocBufs
 int total_up(const ev_config& c) { int u = 1; for (int i = 0; i < c.n_up; ++i) u *= c.up_rates[i]; return u; }
 
 void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs& vb) {
-    vb.pre = ap.rows(Rf, c.up_init_ch, 2);
-    if (keep) vb.pre_tap = ap.rows(Rf, c.up_init_ch, 4);
+    const bool x3 = c.vocoder_precision == EV_PREC_X3;
+    const size_t ves = x3 ? 4 : 2;
+    vb.pre = ap.rows(Rf, c.up_init_ch, ves);
+    if (keep && !x3) vb.pre_tap = ap.rows(Rf, c.up_init_ch, 4);
     int ch = c.up_init_ch, U = 1;
     size_t max_elems = 0;
     for (int i = 0; i < c.n_up; ++i) {
@@ -587,20 +628,20 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
     for (int i = 0; i < c.n_up; ++i) {
         U *= c.up_rates[i]; ch /= 2;
         if (keep) {
-            vb.xu[i] = ap.rows((size_t)Rf * U, ch, 2);
-            vb.nxt[i] = ap.rows((size_t)Rf * U, ch, 2);
-            vb.mrf_tap[i] = ap.rows((size_t)Rf * U, ch, 4);
+            vb.xu[i] = ap.rows((size_t)Rf * U, ch, ves);
+            vb.nxt[i] = ap.rows((size_t)Rf * U, ch, ves);
+            if (!x3) vb.mrf_tap[i] = ap.rows((size_t)Rf * U, ch, 4);
         }
     }
+    // row pitch differs per stage, so size by elements with the largest pad (C = 256 rows of slack)
+    auto mk2 = [&](size_t es) { Buf b; const size_t pad = (size_t)PAD_ROWS * 512 * es; b.bytes = max_elems * es; b.base = ap.take(pad + b.bytes + pad); b.p = ap.dry ? nullptr : b.base + pad; return b; };
     if (!keep) {
-        // row pitch differs per stage, so size by elements with the largest pad (C = 256 rows of slack)
-        auto mk = [&]() { Buf b; const size_t pad = (size_t)PAD_ROWS * 512 * 2; b.bytes = max_elems * 2; b.base = ap.take(pad + b.bytes + pad); b.p = ap.dry ? nullptr : b.base + pad; return b; };
-        shared_xu = mk(); shared_nxt[0] = mk(); shared_nxt[1] = mk();
+        shared_xu = mk2(ves); shared_nxt[0] = mk2(ves); shared_nxt[1] = mk2(ves);
         for (int i = 0; i < c.n_up; ++i) { vb.xu[i] = shared_xu; vb.nxt[i] = shared_nxt[i & 1]; }
     }
-    auto mk2 = [&](size_t es) { Buf b; const size_t pad = (size_t)PAD_ROWS * 512 * es; b.bytes = max_elems * es; b.base = ap.take(pad + b.bytes + pad); b.p = ap.dry ? nullptr : b.base + pad; return b; };
-    for (int j = 0; j < (c.n_rb == 3 ? 3 : 1); ++j) { vb.tmp[j] = mk2(2); vb.rba[j] = mk2(2); vb.rbb[j] = mk2(2); }   // per ResBlock: they run concurrently
-    if (c.n_rb == 3) { vb.mrf16a = mk2(2); vb.mrf16b = mk2(2); } else vb.mrf32 = mk2(4);
+    const bool per_rb = (c.n_rb == 3) && !x3;      // fp16 mode: the three ResBlocks of a stage run concurrently, each with its own intermediates
+    for (int j = 0; j < (per_rb ? 3 : 1); ++j) { vb.tmp[j] = mk2(ves); vb.rba[j] = mk2(ves); vb.rbb[j] = mk2(ves); }
+    if (per_rb) { vb.mrf16a = mk2(2); vb.mrf16b = mk2(2); } else vb.mrf32 = mk2(4);
     vb.wavrows = ap.rows((size_t)Rf * total_up(c), 1, 4);
 }
 
@@ -687,9 +728,36 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
     if (cfg->abi_version != EV_ABI_VERSION) return fail(nullptr, "ev_create: abi_version %d != %d", cfg->abi_version, EV_ABI_VERSION);
     if (cfg->hidden != 384 || cfg->heads != 8) return fail(nullptr, "ev_create: only hidden=384 / heads=8 (d_k=48) kernels are built");
     if (cfg->hidden % 128 || cfg->n_mels > MEL_PAD) return fail(nullptr, "ev_create: unsupported shape");
+    if (cfg->n_up < 1 || cfg->n_up > 4 || cfg->n_rb < 1 || cfg->n_rb > 3 || cfg->n_rb_dils < 1 || cfg->n_rb_dils > 4)
+        return fail(nullptr, "ev_create: generator layout outside the built range (n_up 1-4, n_rb 1-3, dilations 1-4)");
     for (int i = 0; i < cfg->n_up; ++i)
         if (cfg->up_kernels[i] != 2 * cfg->up_rates[i] || (cfg->up_rates[i] & (cfg->up_rates[i] - 1)))
             return fail(nullptr, "ev_create: upsample stage %d must have kernel = 2*stride and a power-of-two stride", i);
+    // shapes the kernels would silently mishandle are rejected here (not discovered as garbage audio):
+    //  * conv_post and the last stage exist for 32 channels only; every stage needs C % 32 == 0
+    //  * GAP zero rows between utterances must cover every token- / frame-rate conv halo
+    //  * a generator conv's span (k-1)*dilation must fit the 64 staged halo rows and the stage's gap rows
+    if ((cfg->up_init_ch >> cfg->n_up) != 32 || (cfg->up_init_ch & (cfg->up_init_ch - 1)))
+        return fail(nullptr, "ev_create: upsample_initial_channel / 2^n_up must be 32 (got %d / 2^%d)", cfg->up_init_ch, cfg->n_up);
+    if ((cfg->ffn_kernel - 1) / 2 > GAP || (cfg->var_embed_kernel - 1) / 2 > GAP || (cfg->var_kernel - 1) / 2 > GAP ||
+        !(cfg->ffn_kernel & 1) || !(cfg->var_embed_kernel & 1))
+        return fail(nullptr, "ev_create: token / frame-rate conv kernels must be odd and <= %d taps", 2 * GAP + 1);
+    {
+        int U = 1;
+        for (int i = 0; i < cfg->n_up; ++i) {
+            U *= cfg->up_rates[i];
+            for (int j = 0; j < cfg->n_rb; ++j)
+                for (int d = 0; d < cfg->n_rb_dils; ++d) {
+                    const int k = cfg->rb_kernels[j], span = (k - 1) * cfg->rb_dils[j][d];
+                    if (!(k & 1) || k < 1 || cfg->rb_dils[j][d] < 1 || span > 64 || span / 2 > GAP * U)
+                        return fail(nullptr, "ev_create: ResBlock kernel %d / dilation %d at stage %d exceeds the staged halo", k, cfg->rb_dils[j][d], i);
+                }
+        }
+    }
+    if (cfg->decoder_precision != EV_PREC_F16 && cfg->decoder_precision != EV_PREC_F32 && cfg->decoder_precision != EV_PREC_X3)
+        return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
+    if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3)
+        return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16 or EV_PREC_X3");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));
@@ -701,6 +769,11 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
         return fail(nullptr, "ev_create: cannot create stream on device %d", device_id);
     }
     h->stream = h->own_stream;
+    if (init_device_kernels(device_id) != 0) {
+        (void)hipStreamDestroy(h->own_stream);
+        delete h;
+        return fail(nullptr, "ev_create: kernel setup failed on device %d (large-LDS opt-in)", device_id);
+    }
     for (int j = 0; j < 2; ++j) {
         if (hipStreamCreateWithFlags(&h->aux[j], hipStreamNonBlocking) != hipSuccess) h->aux[j] = nullptr;
         (void)hipEventCreateWithFlags(&h->ev_join[j], hipEventDisableTiming);
@@ -806,12 +879,13 @@ static int finish_wav(ev_handle* h, VocBufs& vb, float* d_wav, int16_t* d_i16, i
 
 static void register_voc_taps(ev_handle* h, VocBufs& vb) {
     const ev_config& c = h->cfg;
-    add_tap(h, "voc_pre", vb.pre_tap.p, DT_F32, c.up_init_ch, c.up_init_ch, 1, 0);
+    const bool x3 = c.vocoder_precision == EV_PREC_X3;      // split-precision mode: the stored tensors ARE the raw module outputs
+    add_tap(h, "voc_pre", x3 ? vb.pre.p : vb.pre_tap.p, DT_F32, c.up_init_ch, c.up_init_ch, 1, 0);
     int ch = c.up_init_ch, U = 1;
     for (int i = 0; i < c.n_up; ++i) {
         U *= c.up_rates[i]; ch /= 2;
-        add_tap(h, ("voc_up" + std::to_string(i)).c_str(), vb.xu[i].p, DT_F16, ch, ch, 2 + i, ilog2(U));
-        add_tap(h, ("voc_mrf" + std::to_string(i)).c_str(), vb.mrf_tap[i].p, DT_F32, ch, ch, 2 + i, ilog2(U));
+        add_tap(h, ("voc_up" + std::to_string(i)).c_str(), vb.xu[i].p, x3 ? DT_F32 : DT_F16, ch, ch, 2 + i, ilog2(U));
+        add_tap(h, ("voc_mrf" + std::to_string(i)).c_str(), x3 ? vb.nxt[i].p : vb.mrf_tap[i].p, DT_F32, ch, ch, 2 + i, ilog2(U));
     }
 }
 
@@ -821,6 +895,7 @@ int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32
     HIPCHK(h, hipSetDevice(h->device));
     const ev_config& c = h->cfg;
     const bool keep = c.keep_stages != 0;
+    const bool voc_x3 = c.vocoder_precision == EV_PREC_X3;
     const int U = total_up(c);
     profiling_reset(h);
     h->taps.clear();
@@ -845,7 +920,7 @@ int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32
         d_eoff = ap.arr<int64_t>(B);
         d_scr = ap.arr<int64_t>(3 * (size_t)B + 8);
         if (!(flags & EV_FLAG_DEVICE_INPUTS)) d_melin = ap.take((size_t)eo * es);
-        mel16 = ap.rows(Rf, MEL_PAD, 2);
+        mel16 = ap.rows(Rf, MEL_PAD, voc_x3 ? 4 : 2);      // the generator's input rows (fp32 in the split-precision mode)
         plan_vocoder(ap, c, Rf, keep, vb);
         d_wav = ap.arr<float>((size_t)h->total_frames * U);
         d_i16 = ap.arr<int16_t>((size_t)h->total_frames * U);
@@ -857,12 +932,14 @@ int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32
     if (!(flags & EV_FLAG_DEVICE_INPUTS)) { HIPCHK(h, hipMemcpyAsync(d_melin, mel, (size_t)eo * es, hipMemcpyHostToDevice, h->stream)); melsrc = d_melin; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     region_begin(h, "total");
-    launch_mel_to_rows(melsrc, mel_is_f16, d_eoff, h->d_frm_seq, h->d_frm_pos, h->d_mel_len, mel16.p, Rf, c.n_mels, MEL_PAD, h->stream);
+    launch_mel_to_rows(melsrc, mel_is_f16, d_eoff, h->d_frm_seq, h->d_frm_pos, h->d_mel_len, mel16.p, voc_x3 ? 1 : 0, Rf, c.n_mels, MEL_PAD, h->stream);
     region_begin(h, "vocoder");
     if (run_vocoder(h, mel16, Rf, (double)h->total_frames, vb, keep)) return -1;
+    HIPCHK(h, hipGetLastError());       // a rejected launch (bad configuration, missing LDS opt-in) must not return stale audio
     region_end(h, "vocoder");
     memset(out, 0, sizeof *out);
     if (finish_wav(h, vb, d_wav, d_i16, d_scr, flags, out)) return -1;
+    HIPCHK(h, hipGetLastError());
     region_end(h, "total");
     HIPCHK(h, hipStreamSynchronize(h->stream));
     profiling_collect(h);
@@ -882,7 +959,8 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     const int C = c.hidden, U = total_up(c);
     const bool keep = c.keep_stages != 0;
     const bool dev_in = (flags & EV_FLAG_DEVICE_INPUTS) != 0;
-    const int dec_prec = c.decoder_precision == EV_PREC_F32 ? DT_F32 : DT_F16;
+    const int dec_prec = c.decoder_precision == EV_PREC_F16 ? DT_F16 : DT_F32;      // X3 and F32 both keep fp32 activations
+    const bool voc_x3 = c.vocoder_precision == EV_PREC_X3;
     profiling_reset(h);
     h->taps.clear();
     h->B = B;
@@ -899,6 +977,12 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     const int Rt = (int)align_up((size_t)rows, ROW_ALIGN);
     h->Rt = Rt;
     if ((flags & EV_FLAG_FORCED_DURATIONS) && (int64_t)h->forced_dur.size() != NT) return fail(h, "forced durations: expected %d values", NT);
+    if (!dev_in) {      // nn.Embedding raises IndexError on these (model_open_source.py:107,109); device inputs are clamped by the kernels
+        for (int j = 0; j < NT; ++j)
+            if (ling[j] < 0 || ling[j] >= c.n_vocab) return fail(h, "ev_synthesize: phoneme id %lld at position %d outside [0, %d)", (long long)ling[j], j, c.n_vocab);
+        for (int b = 0; b < B; ++b)
+            if (speaker[b] < 0 || speaker[b] >= c.n_speaker) return fail(h, "ev_synthesize: speaker id %lld of utterance %d outside [0, %d)", (long long)speaker[b], b, c.n_speaker);
+    }
     if (ensure_pe(h, max_tok)) return -1;
 
     // ---------------- phase 1: token-rate arena
@@ -959,14 +1043,15 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     float alphas[2];
     if (get_scalar(h, "enc.alpha", &alphas[0]) || get_scalar(h, "dec.alpha", &alphas[1])) return -1;
     { KScope ks(h, "embed_pe", 0, (double)NT * C * 12.0);
-      launch_embed_pe(tb.d_ling, h->d_cu, h->d_tok_seq, h->d_tok_pos, tok_emb, h->pe_dev, alphas[0], (float*)tb.x.p, keep ? (float*)tb.tokemb_tap.p : nullptr, Rt, C, h->stream); }
+      launch_embed_pe(tb.d_ling, h->d_cu, h->d_tok_seq, h->d_tok_pos, tok_emb, c.n_vocab, h->pe_dev, alphas[0], (float*)tb.x.p, keep ? (float*)tb.tokemb_tap.p : nullptr, Rt, C, h->stream); }
     if (run_stack(h, "enc", c.enc_layers, DT_F32, trc, tb.x, tb.hb, tb.qkv, tb.ctx, tb.ffn, tb.y, nullptr, keep ? &tb.ltaps : nullptr)) return -1;
+    HIPCHK(h, hipGetLastError());
     region_end(h, "encoder");
     region_begin(h, "variance");
     // embed_projection1 (model_open_source.py:109-111): time-varying part as a GEMM, conditioning part as a per-utterance vector
     WPTR(wcond, float, "proj.wcond"); WPTR(bproj, float, "proj.b"); WPTR(wproj, char, "proj.w32");
     { KScope ks(h, "cond_vector", 2.0 * B * C * (C + 2.0 * c.bert_dim), 0);
-      launch_cond_vector(tb.d_spk, tb.d_style, tb.d_content, spk_emb, wcond, bproj, tb.d_u, B, C, c.bert_dim, h->stream); }
+      launch_cond_vector(tb.d_spk, tb.d_style, tb.d_content, spk_emb, c.n_speaker, wcond, bproj, tb.d_u, B, C, c.bert_dim, h->stream); }
     {
         ConvGemmParams p = gemm_defaults();
         p.dtype = DT_F32; p.A = tb.y.p; p.lda = C; p.W = wproj; p.M = Rt; p.N = C; p.K = C; p.row_valid = h->d_tok_valid;
@@ -998,6 +1083,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     { KScope ks(h, "durations", 0, 0);
       launch_durations((const float*)tb.logd.p, h->d_tok_off, h->d_tok_len, B, alpha, (flags & EV_FLAG_FORCED_DURATIONS) ? tb.d_forced : nullptr,
                        h->d_cu, tb.d_dur, tb.d_logd_packed, (float*)tb.centre.p, h->d_mel_len, h->stream); }
+    HIPCHK(h, hipGetLastError());
     region_end(h, "variance");
     // the reference has the same host sync here (alignment.py:195 `.item()`)
     h->mel_lens.resize(B);
@@ -1046,9 +1132,12 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         WPTR(wm, char, dec_prec == DT_F16 ? "to_mel.w16" : "to_mel.w32"); WPTR(bm, float, "to_mel.b");
         ConvGemmParams p = gemm_defaults();
         p.dtype = dec_prec; p.A = fb.y.p; p.lda = C; p.W = wm; p.bias = bm; p.M = Rf; p.N = MEL_PAD; p.K = C; p.row_valid = h->d_frm_valid;
-        p.out32 = (float*)fb.mel32.p; p.out16 = fb.mel16.p; p.ldo = MEL_PAD;
+        p.out32 = (float*)fb.mel32.p; p.ldo = MEL_PAD;
+        if (!voc_x3) p.out16 = fb.mel16.p;            // the fp16 generator reads fp16 mel rows, the split-precision one the fp32 rows
+        if (dec_prec == DT_F32 && tok_weights(h, "to_mel.w", p)) return -1;
         if (gemm(h, dec_prec == DT_F16 ? "dec_f16_gemm" : "dec_f32_gemm", p, (double)h->total_frames)) return -1;
     }
+    HIPCHK(h, hipGetLastError());
     region_end(h, "decoder");
     region_end(h, "am");
     // packed outputs
@@ -1058,9 +1147,11 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     memset(out, 0, sizeof *out);
     if (!(flags & EV_FLAG_NO_VOCODER)) {
         region_begin(h, "vocoder");
-        if (run_vocoder(h, fb.mel16, Rf, (double)h->total_frames, vb, keep)) return -1;
+        if (run_vocoder(h, voc_x3 ? fb.mel32 : fb.mel16, Rf, (double)h->total_frames, vb, keep)) return -1;
+        HIPCHK(h, hipGetLastError());
         region_end(h, "vocoder");
         if (finish_wav(h, vb, fb.d_wav, fb.d_i16, tb.d_scr, flags, out)) return -1;
+        HIPCHK(h, hipGetLastError());
     }
     region_end(h, "total");
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1126,7 +1217,8 @@ int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* stream) {
     memcpy(&p, d, sizeof p);
     const int es = p.dtype == DT_F16 ? 2 : 4;
     if (p.M % ROW_ALIGN || p.N % 32 || (p.K * es) % 64 || (p.taps - 1) * p.dil > 64) return -2;
-    if (p.dtype == DT_F32S && (p.K % 32 || p.N % 64 || !p.W_lo)) return -2;
+    if (p.dtype == DT_F32S && (p.K % 32 || !p.W_lo)) return -2;
+    if (p.pro_lrelu && !(p.pro_slope >= 0.f && p.pro_slope <= 1.f)) return -2;
     launch_conv_gemm(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -685,9 +685,9 @@ static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmParams p) {
     constexpr int TT = 64, TC = BN / 2, MT = 4, NT = TC / 16;
-    constexpr int SLAB = BM + MAX_SPAN, XCH = SLAB * 4 / 256, WCH = BN * 4 / 256;
+    constexpr int SLAB = BM + MAX_SPAN, XCH = SLAB * 4 / 256;
     constexpr int XBUF = SLAB * 64, WBUF = BN * 64;
-    static_assert(BM == 128 && WCH == 1 && XCH == 3, "tile shape");
+    static_assert(BM == 128 && (BN == 64 || BN == 32) && XCH == 3, "tile shape");      // BN = 32: the C = 32 layers of the generator's last stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xh = smem;                    // [2][SLAB][64]  hi parts
     char* Xl = Xh + 2 * XBUF;           // [2][SLAB][64]  lo parts
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
         xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + rs) * a_pitch + part * 32;
         xdst[i] = swz(r, part);
     }
-    const int wr_ = tid >> 2, wp_ = tid & 3;
+    const int wr_ = (tid >> 2) % BN, wp_ = tid & 3;      // BN = 32: threads 128-255 duplicate the chunks of threads 0-127 (no predicate)
     const long wsrc_off = (long)(n0 + wr_) * w_row_pitch + wp_ * 16;
     const int wdst = swz(wr_, wp_);
     const char* Whg = reinterpret_cast<const char*>(p.W);
@@ -735,7 +735,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
     }
 #define EV_S_SPLIT_STORE(XA, XB, DST, BUF)                                                       \
     {                                                                                            \
-        const float f_[8] = {XA.x, XA.y, XA.z, XA.w, XB.x, XB.y, XB.z, XB.w};                    \
+        float f_[8] = {XA.x, XA.y, XA.z, XA.w, XB.x, XB.y, XB.z, XB.w};                          \
+        if (p.pro_lrelu) {          /* leaky-relu on the fp32 value, BEFORE the split (slope in [0, 1]: checked by the launcher) */ \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) f_[e] = fmaxf(f_[e], f_[e] * p.pro_slope); \
+        }                                                                                        \
         half8 hi_, lo_;                                                                          \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                          \
             const _Float16 h_ = (_Float16)f_[e];                                                 \
@@ -833,14 +836,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
 #endif
 }
 
-template <int EPI>
-static void launch_split_epi(const ConvGemmParams& p, hipStream_t s) {
-    constexpr int BM = 128, BN = 64;
-    const size_t lds = 4 * (size_t)(BM + MAX_SPAN) * 64 + 4 * (size_t)BN * 64;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)conv_gemm_split_kernel<BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+template <int BN, int EPI>
+static void launch_split_bn(const ConvGemmParams& p, hipStream_t s) {
+    constexpr int BM = 128;
+    size_t lds = 4 * (size_t)(BM + MAX_SPAN) * 64 + 4 * (size_t)BN * 64;
+    const size_t epi = 4 * (size_t)(32 * ((BN / 2) * 4 + 16));
+    if (epi > lds) lds = epi;
+    static_assert(4 * (size_t)(BM + MAX_SPAN) * 64 + 4 * (size_t)BN * 64 <= 65536, "within the default dynamic-LDS limit: no per-device opt-in needed");
     const int grid = (p.M / BM) * (p.N / BN);
     hipLaunchKernelGGL((conv_gemm_split_kernel<BM, BN, EPI>), dim3(grid), dim3(256), lds, s, p);
+}
+template <int EPI>
+static void launch_split_epi(const ConvGemmParams& p, hipStream_t s) {
+    if (p.N % 64 == 0) launch_split_bn<64, EPI>(p, s);
+    else launch_split_bn<32, EPI>(p, s);
 }
 
 static void launch_split(const ConvGemmParams& p, hipStream_t s) {
@@ -1147,22 +1156,23 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
 }
 
 static size_t pair_lds_bytes(int k) { return 2 * (size_t)k * 32 * 64 + 2 * 384 * 64 + 272 * 64 + 8 * 32 * (32 * 4 + 16); }
+static constexpr size_t PAIR64_LDS_BYTES = 2 * 2 * (size_t)(3 * 64 * 64) + 2 * 2 * (size_t)(272 * 64) + 2 * (size_t)(272 * 64);
+
+// Per-device kernel state.  Kernels that use more than 64 KB of dynamic LDS need the opt-in attribute on EVERY device they are
+// launched on, and the persistent kernels size their grid by the device's CU count: both are set up per device (ev_create
+// calls init_device_kernels after hipSetDevice; the launchers look the current device up), never in a function-local static.
+static int g_n_cu[64];
+static bool g_dev_ready[64];
+static int current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < 64) ? d : 0; }
+
+static int device_cus() {
+    const int d = current_device();
+    if (!g_dev_ready[d]) (void)init_device_kernels(d);       // per-kernel test entry points without a handle
+    return g_n_cu[d] > 0 ? g_n_cu[d] : 256;
+}
 
 void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-        // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
-#define EV_PAIR_ATTR(KK)                                                                                              \
-    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK)); \
-    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK)); \
-    (void)hipFuncSetAttribute((const void*)resblock_pair_c32_kernel<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes(KK));
-        EV_PAIR_ATTR(3) EV_PAIR_ATTR(7) EV_PAIR_ATTR(11)
-#undef EV_PAIR_ATTR
-    }
+    const int n_cu = device_cus();
     const int h2 = (p.k - 1) / 2, bmo = 256 - 2 * h2;
     const int ntiles = (p.M + bmo - 1) / bmo;
     const int grid = ntiles < n_cu ? ntiles : n_cu;
@@ -1445,19 +1455,28 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
 #undef EV_P64_VMASK
 }
 
+int init_device_kernels(int device) {
+    if (device < 0 || device >= 64) return -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+    g_n_cu[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipSuccess;
+    auto attr = [&](const void* fn, size_t bytes) { const hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (r != hipSuccess) e = r; };
+#define EV_PAIR_ATTR(KK)                                                         \
+    attr((const void*)resblock_pair_c32_kernel<KK, 0>, pair_lds_bytes(KK));      \
+    attr((const void*)resblock_pair_c32_kernel<KK, 1>, pair_lds_bytes(KK));      \
+    attr((const void*)resblock_pair_c32_kernel<KK, 2>, pair_lds_bytes(KK));
+    EV_PAIR_ATTR(3) EV_PAIR_ATTR(7) EV_PAIR_ATTR(11)
+#undef EV_PAIR_ATTR
+    attr((const void*)resblock_pair_c64_kernel<3, 0>, PAIR64_LDS_BYTES);
+    attr((const void*)resblock_pair_c64_kernel<3, 1>, PAIR64_LDS_BYTES);
+    attr((const void*)resblock_pair_c64_kernel<3, 2>, PAIR64_LDS_BYTES);
+    g_dev_ready[device] = (e == hipSuccess);
+    return e == hipSuccess ? 0 : -1;
+}
 void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s) {
-    constexpr int K = 3;
-    const size_t bytes = 2 * 2 * (size_t)(K * 64 * 64) + 2 * 2 * (size_t)(272 * 64) + 2 * (size_t)(272 * 64);
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-        (void)hipFuncSetAttribute((const void*)resblock_pair_c64_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        (void)hipFuncSetAttribute((const void*)resblock_pair_c64_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        (void)hipFuncSetAttribute((const void*)resblock_pair_c64_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    }
+    const size_t bytes = PAIR64_LDS_BYTES;
+    const int n_cu = device_cus();
     const int bmo = 256 - 2;
     const int ntiles = (p.M + bmo - 1) / bmo;
     const int grid = ntiles < n_cu ? ntiles : n_cu;

@@ -39,6 +39,8 @@ struct ConvGemmParams {
     int reserved1;
 };
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
+// per-device setup of the kernels in ev_gemm.hip (large-LDS opt-in, CU count of the persistent kernels); 0 = OK
+int init_device_kernels(int device);
 
 // Fused HiFi-GAN ResBlock1 pair for C = 32 (reference models/hifigan/models.py:50-57, one iteration of the zip loop):
 //     xt = leaky_relu(c1(leaky_relu(x, .1)) + b1, .1);   out = epilogue(c2(xt) + b2 + x)
@@ -72,7 +74,7 @@ void launch_layernorm(const LayerNormParams& p, hipStream_t s);
 
 // token embedding gather + alpha * PE[pos] (reference model_open_source.py:107, encoder.py:257-261)
 void launch_embed_pe(const int64_t* ling_packed, const int32_t* cu_seqlens_dev, const int32_t* row_seq /* -1 = gap */,
-                     const int32_t* row_pos, const float* emb, const float* pe, float alpha, float* out, float* tap_out,
+                     const int32_t* row_pos, const float* emb, int n_vocab, const float* pe, float alpha, float* out, float* tap_out,
                      int rows, int C, hipStream_t s);
 
 // Self-attention, one (utterance, head, 64-query tile) per wave; fp32 math, online softmax.
@@ -86,7 +88,7 @@ void launch_attention(const AttnParams& p, hipStream_t s);
 
 // u[b, :] = bias + Wspk . spk_emb[speaker[b]] + Wsty . style[b] + Wcon . content[b]
 // (columns 384..2303 of embed_projection1, reference model_open_source.py:110-111)
-void launch_cond_vector(const int64_t* speaker, const float* style, const float* content, const float* spk_emb,
+void launch_cond_vector(const int64_t* speaker, const float* style, const float* content, const float* spk_emb, int n_speaker,
                         const float* Wcond /* [C][C + 2*bert] */, const float* bias, float* u, int B, int C, int bert,
                         hipStream_t s);
 
@@ -108,12 +110,13 @@ void launch_gauss_upsample(const float* xvar, const float* centre_rows, const in
 
 // mel (B x (n_mels, T_b), fp32/fp16) -> channels-last fp16 [rows][ldo] with zero gaps and zero pad channels
 void launch_mel_to_rows(const void* mel, int is_f16, const int64_t* mel_elem_off, const int32_t* frm_row_seq,
-                        const int32_t* frm_row_pos, const int32_t* mel_len, void* out16, int rows, int n_mels, int ldo,
+                        const int32_t* frm_row_pos, const int32_t* mel_len, void* out, int out_f32, int rows, int n_mels, int ldo,
                         hipStream_t s);
 
-// conv_post: leaky-relu'd input [rows][C] fp16 -> Conv1d(C->1, k) -> tanh -> wav fp32 (+ int16)
-void launch_conv_post(const void* x16, int ldx, const float* w /* [k][C] */, float bias, int k, const uint8_t* row_valid,
-                      int valid_shift, float* wav_rows, int rows, int C, hipStream_t s);
+// conv_post: input [rows][C] -> Conv1d(C->1, k) -> tanh -> wav fp32.  fp16 input: already leaky-relu'd by its producer;
+// fp32 input (split-precision mode): raw MRF mean, leaky_relu(pre_slope) applied while reading (pre_slope in [0, 1])
+void launch_conv_post(const void* x, int is_f32, int ldx, const float* w /* [k][C] */, float bias, int k, float pre_slope,
+                      const uint8_t* row_valid, int valid_shift, float* wav_rows, int rows, int C, hipStream_t s);
 
 // gather valid rows of a [rows][ld] buffer (fp16 or fp32) into a packed fp32 [n_valid][C] host-visible buffer
 void launch_pack_rows(const void* src, int dtype, int ld, int C, const int64_t* seq_row_off /* per utterance first row */,

@@ -89,7 +89,7 @@ void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
 // ------------------------------------------------------------------ embedding + positional encoding
 // reference model_open_source.py:107 (src_word_emb) and modules/encoder.py:257-261 (x + alpha * pe[t])
 __global__ __launch_bounds__(256) void embed_pe_kernel(const int64_t* ling, const int32_t* cu, const int32_t* row_seq,
-                                                       const int32_t* row_pos, const float* emb, const float* pe, float alpha,
+                                                       const int32_t* row_pos, const float* emb, int n_vocab, const float* pe, float alpha,
                                                        float* out, float* tap, int rows, int C) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const int64_t* ling, cons
         return;
     }
     const int pos = row_pos[row];
-    const long tok = ling[cu[b] + pos];
+    // host inputs are range-checked by ev_synthesize (nn.Embedding's IndexError); device inputs cannot be without a sync, so an
+    // out-of-range id is clamped instead of reading outside the table
+    const long tok = min(max(ling[cu[b] + pos], 0L), (long)n_vocab - 1);
     const float* e = emb + tok * C;
     const float* pr = pe + (long)pos * C;
     for (int c = lane * 2; c < C; c += 128) {
@@ -115,8 +117,8 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const int64_t* ling, cons
     }
 }
 void launch_embed_pe(const int64_t* ling, const int32_t* cu, const int32_t* row_seq, const int32_t* row_pos, const float* emb,
-                     const float* pe, float alpha, float* out, float* tap_out, int rows, int C, hipStream_t s) {
-    hipLaunchKernelGGL(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ling, cu, row_seq, row_pos, emb, pe, alpha, out,
+                     int n_vocab, const float* pe, float alpha, float* out, float* tap_out, int rows, int C, hipStream_t s) {
+    hipLaunchKernelGGL(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ling, cu, row_seq, row_pos, emb, n_vocab, pe, alpha, out,
                        tap_out, rows, C);
 }
 
@@ -515,7 +517,7 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
 // reference model_open_source.py:109-111: the speaker/style/content part of embed_projection1's input is
 // constant over time, so its contribution (plus the bias) is one vector per utterance.
 __global__ __launch_bounds__(256) void cond_vector_kernel(const int64_t* speaker, const float* style, const float* content,
-                                                          const float* spk_emb, const float* Wcond, const float* bias, float* u,
+                                                          const float* spk_emb, int n_speaker, const float* Wcond, const float* bias, float* u,
                                                           int C, int bert) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void cond_vector_kernel(const int64_t* speaker
     if (c >= C) return;
     const int ncond = C + 2 * bert;
     const float* w = Wcond + (long)c * ncond;
-    const float* se = spk_emb + speaker[b] * C;
+    const float* se = spk_emb + min(max(speaker[b], 0L), (long)n_speaker - 1) * C;      // clamped like the token ids (embed_pe_kernel)
     float a = 0.f;
     for (int i = lane; i < C; i += 64) a = fmaf(w[i], se[i], a);
     for (int i = lane; i < bert; i += 64) a = fmaf(w[C + i], style[(long)b * bert + i], a);
@@ -531,10 +533,10 @@ __global__ __launch_bounds__(256) void cond_vector_kernel(const int64_t* speaker
     a = wave_sum(a);
     if (lane == 0) u[(long)b * C + c] = a + bias[c];
 }
-void launch_cond_vector(const int64_t* speaker, const float* style, const float* content, const float* spk_emb, const float* Wcond,
-                        const float* bias, float* u, int B, int C, int bert, hipStream_t s) {
-    hipLaunchKernelGGL(cond_vector_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, speaker, style, content, spk_emb, Wcond, bias, u,
-                       C, bert);
+void launch_cond_vector(const int64_t* speaker, const float* style, const float* content, const float* spk_emb, int n_speaker,
+                        const float* Wcond, const float* bias, float* u, int B, int C, int bert, hipStream_t s) {
+    hipLaunchKernelGGL(cond_vector_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, speaker, style, content, spk_emb, n_speaker, Wcond,
+                       bias, u, C, bert);
 }
 
 // ------------------------------------------------------------------ pitch / energy embedding add
@@ -629,15 +631,19 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* log_d, cons
         }
         if (tid == 0) mel_len[b] = all_zero ? n : total_s;
     } else {
-        // general alpha: sequential fp32 cumsum like torch.cumsum on CPU
+        // general alpha (an extension: the reference's inference branch never scales, model_open_source.py:142): sequential fp32
+        // cumsum for the centres; the length follows alignment.py:194 torch.sum(ds * alpha).int() evaluated in double, so that it
+        // does not depend on the order of a float reduction (the CPU oracle does the same)
         if (tid == 0) {
             float cs = 0.f;
+            double tot = 0.0;
             for (int j = 0; j < n; ++j) {
                 const float d = all_zero ? 1.0f : (float)dur_packed[c0 + j] * alpha;
                 cs += d;
+                tot += (double)d;
                 centre_rows[off + j] = cs - d / 2.0f;
             }
-            mel_len[b] = (int)cs;
+            mel_len[b] = (int)tot;
         }
     }
 }
@@ -723,9 +729,10 @@ void launch_gauss_upsample(const float* xvar, const float* centre_rows, const in
 }
 
 // ------------------------------------------------------------------ mel (B x (n_mels, T)) -> channels-last rows
+template <typename TO>
 __global__ __launch_bounds__(256) void mel_to_rows_kernel(const void* mel, int is_f16, const int64_t* mel_elem_off,
                                                           const int32_t* row_seq, const int32_t* row_pos, const int32_t* mel_len,
-                                                          __half* out, int rows, int n_mels, int ldo) {
+                                                          TO* out, int rows, int n_mels, int ldo) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)rows * ldo) return;
     const int row = (int)(idx / ldo), c = (int)(idx % ldo);
@@ -735,34 +742,39 @@ __global__ __launch_bounds__(256) void mel_to_rows_kernel(const void* mel, int i
         const long e = mel_elem_off[b] + (long)c * mel_len[b] + row_pos[row];
         v = is_f16 ? __half2float(reinterpret_cast<const __half*>(mel)[e]) : reinterpret_cast<const float*>(mel)[e];
     }
-    out[idx] = __float2half_rn(v);
+    out[idx] = (TO)v;
 }
 void launch_mel_to_rows(const void* mel, int is_f16, const int64_t* mel_elem_off, const int32_t* frm_row_seq,
-                        const int32_t* frm_row_pos, const int32_t* mel_len, void* out16, int rows, int n_mels, int ldo,
+                        const int32_t* frm_row_pos, const int32_t* mel_len, void* out, int out_f32, int rows, int n_mels, int ldo,
                         hipStream_t s) {
     const long n = (long)rows * ldo;
-    hipLaunchKernelGGL(mel_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel, is_f16, mel_elem_off, frm_row_seq,
-                       frm_row_pos, mel_len, reinterpret_cast<__half*>(out16), rows, n_mels, ldo);
+    if (out_f32)
+        hipLaunchKernelGGL((mel_to_rows_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel, is_f16, mel_elem_off,
+                           frm_row_seq, frm_row_pos, mel_len, reinterpret_cast<float*>(out), rows, n_mels, ldo);
+    else
+        hipLaunchKernelGGL((mel_to_rows_kernel<_Float16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel, is_f16, mel_elem_off,
+                           frm_row_seq, frm_row_pos, mel_len, reinterpret_cast<_Float16*>(out), rows, n_mels, ldo);
 }
 
 // ------------------------------------------------------------------ conv_post + tanh
 // reference models/hifigan/models.py:127-129: leaky_relu(0.01) [fused into the producer] -> Conv1d(C->1,k7,p3) -> tanh.
 // Block = 256 output samples; the (256 + k - 1) x C fp16 input rows are staged in LDS (80-B pitch).
-template <int C>
-__global__ __launch_bounds__(256) void conv_post_kernel(const __half* x, int ldx, const float* w, float bias, int k,
+template <int C, typename T>
+__global__ __launch_bounds__(256) void conv_post_kernel(const T* x, int ldx, const float* w, float bias, int k, float pre_slope,
                                                         const uint8_t* row_valid, int valid_shift, float* wav_rows, int rows) {
-    constexpr int PITCH = C * 2 + 16;
+    constexpr int ES = sizeof(T);
+    constexpr int PITCH = C * ES + 16;
     __shared__ __attribute__((aligned(16))) char xs[(256 + 16) * PITCH];
     __shared__ float ws[16 * C];
     const int tid = threadIdx.x;
     const long r0 = (long)blockIdx.x * 256;
     const int half = (k - 1) / 2;
     const int nrows = 256 + k - 1;
-    constexpr int CPR = C * 2 / 16;   // 16-B chunks per row
+    constexpr int CPR = C * ES / 16;   // 16-B chunks per row
     for (int c = tid; c < nrows * CPR; c += 256) {
         const int r = c / CPR, part = c % CPR;
         *reinterpret_cast<uint4*>(xs + r * PITCH + part * 16) =
-            *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((r0 + r - half) * ldx) * 2 + part * 16);
+            *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((r0 + r - half) * ldx) * ES + part * 16);
     }
     for (int i = tid; i < k * C; i += 256) ws[i] = w[i];
     __syncthreads();
@@ -774,24 +786,34 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const __half* x, int ldx
 #pragma unroll
         for (int part = 0; part < CPR; ++part) {
             const uint4 v = *reinterpret_cast<const uint4*>(xr + part * 16);
-            const __half2* h = reinterpret_cast<const __half2*>(&v);
+            if constexpr (ES == 2) {
+                const __half2* h = reinterpret_cast<const __half2*>(&v);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float2 f = __half22float2(h[e]);
-                a = fmaf(f.x, ws[t * C + part * 8 + e * 2], a);
-                a = fmaf(f.y, ws[t * C + part * 8 + e * 2 + 1], a);
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(h[e]);
+                    a = fmaf(f.x, ws[t * C + part * 8 + e * 2], a);
+                    a = fmaf(f.y, ws[t * C + part * 8 + e * 2 + 1], a);
+                }
+            } else {
+                const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a = fmaf(fmaxf(f[e], f[e] * pre_slope), ws[t * C + part * 4 + e], a);   // leaky_relu of models.py:127
             }
         }
     }
     const bool valid = row_valid[row >> valid_shift] != 0;
     wav_rows[row] = valid ? tanhf(a) : 0.f;
 }
-void launch_conv_post(const void* x16, int ldx, const float* w, float bias, int k, const uint8_t* row_valid, int valid_shift,
-                      float* wav_rows, int rows, int C, hipStream_t s) {
+void launch_conv_post(const void* x, int is_f32, int ldx, const float* w, float bias, int k, float pre_slope, const uint8_t* row_valid,
+                      int valid_shift, float* wav_rows, int rows, int C, hipStream_t s) {
     const int grid = (rows + 255) / 256;
-    if (C == 32)
-        hipLaunchKernelGGL((conv_post_kernel<32>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const __half*>(x16), ldx, w, bias, k,
-                           row_valid, valid_shift, wav_rows, rows);
+    if (C != 32) return;      // ev_create rejects configurations whose last stage is not 32 channels wide
+    if (is_f32)
+        hipLaunchKernelGGL((conv_post_kernel<32, float>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const float*>(x), ldx, w, bias, k,
+                           pre_slope, row_valid, valid_shift, wav_rows, rows);
+    else
+        hipLaunchKernelGGL((conv_post_kernel<32, __half>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const __half*>(x), ldx, w, bias, k,
+                           pre_slope, row_valid, valid_shift, wav_rows, rows);
 }
 
 // ------------------------------------------------------------------ packing helpers

@@ -14,8 +14,22 @@ class EVError(RuntimeError):
     pass
 
 
+_PREC = {"f16": _ffi.EV_PREC_F16, "f32": _ffi.EV_PREC_F32, "x3": _ffi.EV_PREC_X3}
+
+
+def resolve_precision(precision, decoder_precision, vocoder_precision):
+    """``precision`` is the one-knob form: "fast" = fp16 MFMA operands on the frame-rate path (BASELINE.json's bf16 / fp16
+    configs), "strict" = split precision (three fp16 MFMAs per product on hi/lo parts, fp32 activations: fp32-class accuracy,
+    ~1e-5 relative L2 on the waveform).  ``decoder_precision`` / ``vocoder_precision`` override it per component."""
+    if precision not in (None, "fast", "strict"):
+        raise ValueError("precision must be 'fast' or 'strict'")
+    base = "x3" if precision == "strict" else "f16"
+    return decoder_precision or base, vocoder_precision or base
+
+
 def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages: bool = False,
-                   token_rate: str = "split", vocoder_chunk_mb: int = 0, vocoder_streams: int = 0) -> _ffi.ev_config:
+                   token_rate: str = "split", vocoder_chunk_mb: int = 0, vocoder_streams: int = 0,
+                   vocoder_precision: str = "f16") -> _ffi.ev_config:
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
     for f in ("n_vocab", "n_speaker", "n_mels", "hidden", "heads", "enc_layers", "dec_layers", "ffn_kernel", "bert_dim",
@@ -31,7 +45,10 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages
         for d, v in enumerate(shapes.rb_dils[j]):
             cfg.rb_dils[j][d] = int(v)
     cfg.sample_rate = int(shapes.sr)
-    cfg.decoder_precision = {"f16": _ffi.EV_PREC_F16, "f32": _ffi.EV_PREC_F32}[decoder_precision]
+    cfg.decoder_precision = _PREC[decoder_precision]
+    if vocoder_precision not in ("f16", "x3"):
+        raise ValueError("vocoder_precision must be 'f16' or 'x3'")
+    cfg.vocoder_precision = _PREC[vocoder_precision]
     cfg.keep_stages = 1 if keep_stages else 0
     cfg.vocoder_chunk_mb = int(vocoder_chunk_mb)
     cfg.vocoder_streams = int(vocoder_streams)
@@ -42,13 +59,16 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages
 class EVEngine:
     """One handle = one GPU + one stream + one workspace (include/evhip.h).  Not thread-safe."""
 
-    def __init__(self, shapes: Optional[EVShapes] = None, device_id: int = 0, decoder_precision: str = "f16",
+    def __init__(self, shapes: Optional[EVShapes] = None, device_id: int = 0, decoder_precision: Optional[str] = None,
                  keep_stages: bool = False, token_rate: str = "split", vocoder_chunk_mb: int = 0,
-                 vocoder_streams: int = 0):
+                 vocoder_streams: int = 0, vocoder_precision: Optional[str] = None, precision: Optional[str] = None):
         self.shapes = shapes or EVShapes()
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
-        cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate, vocoder_chunk_mb, vocoder_streams)
+        decoder_precision, vocoder_precision = resolve_precision(precision, decoder_precision, vocoder_precision)
+        self.decoder_precision, self.vocoder_precision = decoder_precision, vocoder_precision
+        cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate, vocoder_chunk_mb, vocoder_streams,
+                             vocoder_precision)
         if self._lib.ev_create(device_id, C.byref(cfg), C.byref(self._h)) != 0:
             raise EVError(self._lib.ev_last_error(None).decode())
         self.device_id = device_id

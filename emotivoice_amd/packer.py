@@ -127,6 +127,12 @@ class _Blob:
         self.add(name + "32h", hi, DT_F16)
         self.add(name + "32l", lo, DT_F16)
 
+    def lo(self, name: str, arr: np.ndarray):
+        """low part only (the high part fp16(w) is the tensor's plain fp16 copy): fp16((w - fp16(w)) * 2^11)."""
+        w = np.ascontiguousarray(arr, np.float32)
+        hi = w.astype(np.float16)
+        self.add(name, ((w - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16), DT_F16)
+
     def finish(self) -> Tuple[bytes, dict]:
         n = len(self.items)
         off = 16 + n * _ENTRY.size
@@ -182,6 +188,11 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
                 b.split(f"{short}.{i}.out.w", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
                 b.split(f"{short}.{i}.ffn1.w", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))
                 b.split(f"{short}.{i}.ffn2.w", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
+            else:                    # mel decoder, split-precision mode (EV_PREC_X3): hi = the w16 copy, lo packed here
+                b.lo(f"{short}.{i}.qkv.w32l", np.concatenate(wq, 0)[:, None, :])
+                b.lo(f"{short}.{i}.out.w32l", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
+                b.lo(f"{short}.{i}.ffn1.w32l", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))
+                b.lo(f"{short}.{i}.ffn2.w32l", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
             b.add(f"{short}.{i}.qkv.b", np.concatenate(bq, 0), DT_F32)
             b.both(f"{short}.{i}.out.w", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
             b.add(f"{short}.{i}.out.b", f32(f"{p}.self_attn.linear_out.bias"), DT_F32)
@@ -218,16 +229,22 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
     bm = np.zeros(MEL_PAD, np.float32)
     bm[: s.n_mels] = f32("am.to_mel.bias")
     b.both("to_mel.w", wm)
+    b.lo("to_mel.w32l", wm)
     b.add("to_mel.b", bm, DT_F32)
 
     g = "generator"
-    b.add("voc.pre.w16", _conv_to_gemm(_fold_weight_norm(sd, f"{g}.conv_pre"), MEL_PAD), DT_F16)
+    # every generator conv: fp16 weights ("w16", also the hi part of the split) + the lo part ("w16l") for the split-precision mode
+    wpre = _conv_to_gemm(_fold_weight_norm(sd, f"{g}.conv_pre"), MEL_PAD)
+    b.add("voc.pre.w16", wpre, DT_F16)
+    b.lo("voc.pre.w16l", wpre)
     b.add("voc.pre.b", f32(f"{g}.conv_pre.bias"), DT_F32)
     ch = s.up_init_ch
     nk = len(s.rb_kernels)
     for i, (u, k) in enumerate(zip(s.up_rates, s.up_kernels)):
         assert k == 2 * u, "polyphase packing needs kernel = 2*stride"
-        b.add(f"voc.up{i}.w16", _convT_to_gemm(_fold_weight_norm(sd, f"{g}.ups.{i}"), u), DT_F16)
+        wup = _convT_to_gemm(_fold_weight_norm(sd, f"{g}.ups.{i}"), u)
+        b.add(f"voc.up{i}.w16", wup, DT_F16)
+        b.lo(f"voc.up{i}.w16l", wup)
         b.add(f"voc.up{i}.b", np.tile(f32(f"{g}.ups.{i}.bias"), u), DT_F32)
         ch //= 2
         for j in range(nk):
@@ -235,7 +252,9 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
             for d in range(len(s.rb_dils[j])):
                 for grp, short in (("convs1", "c1"), ("convs2", "c2")):
                     pre = f"{g}.resblocks.{r}.{grp}.{d}"
-                    b.add(f"voc.rb{r}.{short}.{d}.w16", _conv_to_gemm(_fold_weight_norm(sd, pre)), DT_F16)
+                    wrb = _conv_to_gemm(_fold_weight_norm(sd, pre))
+                    b.add(f"voc.rb{r}.{short}.{d}.w16", wrb, DT_F16)
+                    b.lo(f"voc.rb{r}.{short}.{d}.w16l", wrb)
                     b.add(f"voc.rb{r}.{short}.{d}.b", f32(pre + ".bias"), DT_F32)
     wpost = _fold_weight_norm(sd, f"{g}.conv_post")     # [1, C, 7]
     b.add("voc.post.w", np.ascontiguousarray(wpost[0].T), DT_F32)   # [7][C]

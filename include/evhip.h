@@ -62,7 +62,7 @@ typedef struct ev_config {
     int32_t n_rb_dils;          /* 3     */
     int32_t sample_rate;        /* 16000 */
     /* engine options (not in the reference) */
-    int32_t decoder_precision;  /* EV_PREC_F16 (default) or EV_PREC_F32 (strict parity mode) */
+    int32_t decoder_precision;  /* EV_PREC_F16 (default), EV_PREC_X3 (split precision) or EV_PREC_F32 (exact fp32 MFMA) */
     int32_t keep_stages;        /* !=0: keep every Appendix-C stage tap retrievable by ev_get_stage */
     int32_t token_rate_split;   /* 1 (default): fp32 token-rate GEMMs as 3 fp16 MFMAs on hi/lo splits (fp32-level accuracy,
                                    ~4x faster); 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
@@ -73,10 +73,18 @@ typedef struct ev_config {
     int32_t vocoder_streams;    /* 0 (default): the three ResBlocks of a generator stage run concurrently (two internal streams beside
                                    the handle's); 1: everything on the handle's stream.  The pitch / energy predictors use the same two streams beside the
                                    duration predictor. */
-    int32_t reserved[5];
+    int32_t vocoder_precision;  /* EV_PREC_F16 (default): fp16 operands / fp16 activations in HBM, fp32 accumulate;
+                                   EV_PREC_X3: fp32 activations, every product as three fp16 MFMAs on hi/lo splits (fp32-class accuracy) */
+    int32_t reserved[4];
 } ev_config;
 
-enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1 };
+/* Precision of the frame-rate path.  F16: fp16 MFMA operands (what BASELINE.json's bf16 / fp16 configs name).
+ * F32: exact fp32 MFMA (decoder only; v_mfma_f32_16x16x4_f32, 1/16 of the fp16 rate).
+ * X3:  fp32 activations in HBM, weights and activations split into fp16 hi + lo parts, x*w = hi*hi + hi*lo + lo*hi as three
+ *      fp16 MFMAs with fp32 accumulation (2^-22 relative truncation: the fp32 rounding class at 1/3 of the fp16 rate).
+ *      With decoder_precision = vocoder_precision = EV_PREC_X3 ("strict") the waveform matches the fp32 reference to ~1e-5
+ *      relative L2 also on DC-free audio, where fp16 operands measure ~2e-3. */
+enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1, EV_PREC_X3 = 2 };
 
 /* flags for ev_synthesize / ev_vocoder */
 enum {

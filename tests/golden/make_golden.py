@@ -100,6 +100,8 @@ CASES = {
     "n33_bench": (0, "bench", 13, [33], [0]),
     # speed control (alpha scales the float durations before the cumsum, alignment.py:185; mel_len = int(sum))
     "n24_alpha1p3": (0, "stress", 15, [24], [77], 1.3),
+    # zero-mean waveform (conv_post bias = synthetic.ZDC_POST_BIAS): relative L2 without a DC term in the denominator
+    "n28_zero_dc": (0, "parity_zdc", 16, [28], [123]),
 }
 
 

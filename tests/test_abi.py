@@ -37,13 +37,13 @@ def test_struct_layouts_match_the_c_headers(tmp_path):
                    '#include <stddef.h>\n'
                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ev_config), sizeof(ev_result), sizeof(ev_kernel_stat), '
                    'sizeof(ev_conv_gemm_desc), sizeof(ev_res_pair_desc), offsetof(ev_res_pair_desc, epi), offsetof(ev_conv_gemm_desc, add16_a), '
-                   'offsetof(ev_config, vocoder_streams));return 0;}')
+                   'offsetof(ev_config, vocoder_precision));return 0;}')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(_ffi.ev_config), C.sizeof(_ffi.ev_result), C.sizeof(_ffi.ev_kernel_stat), C.sizeof(_ffi.ev_conv_gemm_desc),
                      C.sizeof(_ffi.ev_res_pair_desc), _ffi.ev_res_pair_desc.epi.offset, _ffi.ev_conv_gemm_desc.add16_a.offset,
-                     _ffi.ev_config.vocoder_streams.offset]
+                     _ffi.ev_config.vocoder_precision.offset]
 
 
 def test_default_config_matches_reference_yaml_values():

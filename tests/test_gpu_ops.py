@@ -397,3 +397,62 @@ def test_split_precision_gemm_matches_fp32(lib, M, K, N, taps):
         errs[dtype] = _rel(out.cpu().double(), ref)
     assert errs[2] < 1e-5 and errs[1] < 1e-5, errs
     assert errs[2] < 3e-6, errs          # within a small factor of fp32 rounding
+
+
+@pytest.mark.parametrize("C_,k,dil", [(32, 11, 5), (32, 3, 1), (64, 7, 3), (128, 11, 5), (96, 7, 1)])
+def test_split_precision_generator_convs(lib, C_, k, dil):
+    """The split-precision (EV_PREC_X3) form of the HiFi-GAN ResBlock convs (models/hifigan/models.py:50-57,121-126): fp32
+    activations, leaky-relu applied to the fp32 value while staging (before the hi/lo split), dilated taps, N = 32 (BN = 32
+    tile) and N % 64 == 0, then conv2's epilogue: fp32 residual, 1/3 scale, fp32 accumulate-in, row mask.  fp64 reference."""
+    from emotivoice_amd import _ffi
+    torch.manual_seed(C_ * 100 + k)
+    M = 1024
+    N = 512 if C_ == 96 else C_                      # conv_pre shape: K = 96 (padded mel), N = 512
+    full, x = _padded(M, C_, torch.float32)
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    valid = torch.ones(M // 4, dtype=torch.uint8, device="cuda")
+    valid[:3] = 0
+    valid[100:104] = 0
+    vrow = valid.bool().repeat_interleave(4)
+    w = torch.randn(N, C_, k, device="cuda") / math.sqrt(C_ * k)
+    bias = torch.randn(N, device="cuda")
+    wg = w.permute(0, 2, 1).contiguous()
+    hi = wg.half()
+    lo = ((wg - hi.float()) * 2048.0).half()
+    res = torch.randn(M, N, device="cuda")
+    acc = torch.randn(M, N, device="cuda")
+
+    def call(pro, act, with_res):
+        d = _ffi.ev_conv_gemm_desc()
+        d.dtype, d.A, d.lda, d.W, d.W_lo = 2, x.data_ptr(), C_, hi.data_ptr(), lo.data_ptr()
+        d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), M, N, C_, k, dil, (k - 1) // 2, 1.0
+        d.row_valid, d.valid_shift = valid.data_ptr(), 2
+        if pro:
+            d.pro_lrelu, d.pro_slope = 1, 0.1
+        if act:
+            d.act, d.act_slope = 3, 0.1
+        if with_res:
+            d.res, d.res_dtype, d.ldres = res.data_ptr(), 1, N
+            d.out_scale = 1.0 / 3.0
+            d.acc32, d.ldacc = acc.data_ptr(), N
+        out = torch.full((M, N), 7.0, device="cuda")
+        d.out32, d.ldo = out.data_ptr(), N
+        torch.cuda.synchronize()
+        assert lib.ev_op_conv_gemm(C.byref(d), None) == 0
+        torch.cuda.synchronize()
+        return out
+
+    xin = x.double().cpu()
+    conv = lambda z: F.conv1d(z.t().unsqueeze(0), w.double().cpu(), bias.double().cpu(), dilation=dil, padding=dil * (k - 1) // 2).squeeze(0).t()  # noqa: E731
+    # conv1 form: lrelu -> conv -> lrelu
+    ref1 = _lrelu(conv(_lrelu(xin, 0.1)), 0.1)
+    ref1[~vrow.cpu()] = 0
+    o1 = call(True, True, False)
+    assert _rel(o1.cpu().double(), ref1) < 3e-6, (C_, k, dil)
+    assert float(o1[~vrow].abs().max()) == 0.0
+    # conv2 form: conv + residual, scaled, + running MRF sum
+    ref2 = (conv(xin) + res.double().cpu()) / 3.0 + acc.double().cpu()
+    ref2[~vrow.cpu()] = 0
+    o2 = call(False, False, True)
+    assert _rel(o2.cpu().double(), ref2) < 3e-6, (C_, k, dil)
