@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
 """Throughput of the EmotiVoice hot path (JETSGenerator.forward = acoustic model + HiFi-GAN) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--mode am_vocoder|ragged|vocoder] [--precision fast|strict]
+                                                   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload = BASELINE.json configs[1]: batch 32 x 256 synthetic phonemes, one speaker, AM + vocoder end to
-end, seeded synthetic weights whose duration head gives exactly 4 frames / phoneme (1024 frames = 16.384 s
-of audio per utterance).  One "step" = one ev_synthesize call over the rank's batch with the inputs already
-resident in HBM.  N > 1: utterances are sharded (weak scaling, per-GPU batch fixed); the only collective is
-the start-up broadcast of the packed weight blob over RCCL.  Prints ONE JSON line on rank 0.
+Workloads (BASELINE.json configs; seeded synthetic weights and inputs, nothing is read from disk):
+  am_vocoder (default) -- configs[1]: batch 32 x 256 synthetic phonemes, one speaker, AM + vocoder end to end; the duration head
+              of the "bench" weights gives exactly 4 frames / phoneme (1024 frames = 16.384 s of audio per utterance).
+              N > 1 runs configs[3]: 256 utterances per GPU per step as 8 sub-batches of 32 (2048 over 8 GPUs).
+  ragged   -- configs[2]: batch 256, lengths 64 + (i * 7919 mod 449), speakers i mod 2000, "parity" weights (predicted durations
+              vary: the length regulator's ragged path).
+  vocoder  -- configs[4]: 128 pre-computed 80 x 1024 fp16 mels per GPU through ev_vocoder (1024 over 8 GPUs).
+One "step" = one pass of the rank's batch (all its sub-batches) with the inputs already resident in HBM.  N > 1: utterances are
+sharded (weak scaling, per-GPU work fixed); the only collective is the start-up broadcast of the packed weight blob over RCCL.
+Precision: "fast" = fp16 MFMA operands (the precision BASELINE.json names for these configs), "strict" = split precision
+(fp32 activations, three fp16 MFMAs per product; fp32-class parity, tests/test_gpu_parity.py).  At N = 1 the other precision is
+timed as well and reported under "other_precision".  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -22,13 +30,19 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work per mel frame (SURVEY.md section 8(d) / BASELINE.md section 3)
 VOC_CONV_FLOP_PER_FRAME = 614.105e6 - 0.115e6      # every Conv1d/ConvTranspose1d of the generator except conv_post
-VOC_STAGE3_RB_FLOP_PER_FRAME = (9.437 + 22.020 + 34.603) * 1e6   # stage-3 ResBlocks (C = 32): run by the fused pair kernel
-VOC_STAGE2_K3_RB_FLOP_PER_FRAME = 18.874e6         # stage-2 k = 3 ResBlock (C = 64): run by the C = 64 fused pair kernel
+VOC_STAGE3_RB_FLOP_PER_FRAME = (9.437 + 22.020 + 34.603) * 1e6   # stage-3 ResBlocks (C = 32): run by the fused pair kernel (fast mode)
+VOC_STAGE2_K3_RB_FLOP_PER_FRAME = 18.874e6         # stage-2 k = 3 ResBlock (C = 64): run by the C = 64 fused pair kernel (fast mode)
 VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
-AM_FLOP_PER_UTT = 51.43e9
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0                                  # GB/s
+REFERENCE_CPU_FRAMES_PER_S = 628.0                 # the reference's own JETSGenerator, 8 Xeon cores, B = 1, N = 256
+
+
+def decoder_flops(frames):
+    """Algorithmic FLOPs of the 4-layer mel decoder for one utterance of T frames (SURVEY.md section 8(d) formula)."""
+    T = float(frames)
+    return 2.0 * 4.0 * T * (4 * 384 ** 2 + 2 * T * 384 + 2 * 384 * 1536 * 3)
 
 
 def cpu_baseline(n_utts, phonemes):
@@ -54,10 +68,135 @@ def cpu_baseline(n_utts, phonemes):
         done += 1
         if time.perf_counter() - t0 > 25.0:      # bounded sample: ~10-30 s of CPU work
             break
-    n_utts = done
     dt = time.perf_counter() - t0
     return dict(value=frames / dt, unit="mel-frames/s", cores=cores, kind="port",
-                sample="%d utterances x %d phonemes, B=1 loop, fp32 torch-CPU oracle, %.1f s" % (n_utts, phonemes, dt))
+                sample="%d utterances x %d phonemes, B=1 loop, fp32 torch-CPU oracle, %.1f s" % (done, phonemes, dt),
+                reference_measured_elsewhere=dict(value=REFERENCE_CPU_FRAMES_PER_S, unit="mel-frames/s", cores=8,
+                                                  note="the reference's own JETSGenerator module (kind 'reference') timed in the build "
+                                                       "container, SURVEY.md section 6; /root/reference does not exist on the GPU box"))
+
+
+class Workload:
+    """Device-resident inputs of one rank + the callable that runs one step."""
+
+    def __init__(self, args, eng, rank, dev, torch, _ffi):
+        from emotivoice_amd.synthetic import synth_inputs
+        self.eng, self.mode = eng, args.mode
+        self.calls = []          # one closure per sub-batch
+        self.desc = {}
+        if args.mode == "vocoder":
+            nb = args.batch or 128
+            rng = np.random.default_rng(9 + rank)
+            base = (1.25 * rng.standard_normal((8, 80, 1024)) + 0.08).astype(np.float16)       # mel statistics of the oracle AM (SURVEY 8(d))
+            mel = torch.from_numpy(np.ascontiguousarray(np.concatenate([base[i % 8].ravel() for i in range(nb)]))).to(dev)
+            lens = np.full(nb, 1024, np.int32)
+            self.keep = [mel]
+            self.calls.append(lambda: eng.vocoder_raw(nb, mel.data_ptr(), True, lens, _ffi.EV_FLAG_DEVICE_INPUTS))
+            self.desc = dict(workload="configs[4]: %d pre-computed 80x1024 fp16 mels per GPU, vocoder only" % nb, batch_per_gpu=nb)
+            self.utts_per_step = nb
+            return
+        if args.mode == "ragged":
+            nb = args.batch or 256
+            lens = [64 + ((i + rank * nb) * 7919) % 449 for i in range(nb)]
+            spk = [(i + rank * nb) % 2000 for i in range(nb)]
+            groups = [(lens, spk)]
+            self.desc = dict(workload="configs[2]: batch=%d, mixed 64-512 phoneme lengths, 2000-speaker round-robin, AM+vocoder" % nb,
+                             batch_per_gpu=nb, phonemes_per_step=int(sum(lens)))
+        else:
+            nb = args.batch or 32
+            nsub = args.sub_batches
+            groups = [([args.phonemes] * nb, [0] * nb) for _ in range(nsub)]
+            cfgname = "configs[1]" if nsub == 1 else "configs[3] share"
+            self.desc = dict(workload="%s: %d x batch=%d x %d-phoneme synthetic utterances per GPU per step, 1 speaker, AM+vocoder end-to-end, "
+                                      "4 frames/phoneme" % (cfgname, nsub, nb, args.phonemes),
+                             batch_per_gpu=nb * nsub, sub_batches=nsub, phonemes=args.phonemes)
+        self.keep = []
+        self.utts_per_step = 0
+        for gi, (lens, spk) in enumerate(groups):
+            utts = synth_inputs(1 + rank * 64 + gi, lens, spk)
+            B = len(utts)
+            ling = torch.from_numpy(np.concatenate([u["ling"] for u in utts])).to(dev)
+            cu = np.zeros(B + 1, np.int32)
+            cu[1:] = np.cumsum(lens)
+            spk_t = torch.tensor(spk, dtype=torch.int64, device=dev)
+            style = torch.from_numpy(np.stack([u["style"] for u in utts])).to(dev)
+            content = torch.from_numpy(np.stack([u["content"] for u in utts])).to(dev)
+            self.keep += [ling, spk_t, style, content]
+            self.calls.append(lambda B=B, ling=ling, cu=cu, spk_t=spk_t, style=style, content=content:
+                              eng.synthesize_raw(B, ling.data_ptr(), cu, spk_t.data_ptr(), style.data_ptr(), content.data_ptr(), 1.0,
+                                                 _ffi.EV_FLAG_DEVICE_INPUTS))
+            self.utts_per_step += B
+
+    def step(self):
+        frames = 0
+        for c in self.calls:
+            frames += int(c().total_frames)
+        return frames
+
+
+def timed(work, steps, warmup, sync):
+    for _ in range(warmup):
+        work.step()
+    sync()
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(steps):
+        frames += work.step()
+    sync()
+    return frames, time.perf_counter() - t0
+
+
+def roofline_block(eng, work, torch, strict):
+    """One extra profiled step (hipEvents on the engine's stream around every launch, single stream) -> per-family accounting."""
+    eng.set_profiling(True)
+    res = work.calls[0]()
+    torch.cuda.synchronize()
+    stats = {s["name"]: s for s in eng.kernel_stats()}
+    stages = eng.timings()
+    eng.set_profiling(False)
+    f1 = int(res.total_frames)
+    B = int(res.batch)
+    kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in stats.items()}
+    voc = stats.get("voc_conv_gemm_x3" if strict else "voc_conv_gemm_f16")
+    roof = None
+    if voc and voc["ms"] > 0:
+        pair = stats.get("voc_resblock_pair_c32")
+        pair64 = stats.get("voc_resblock_pair_c64")
+        # algorithmic FLOPs of what THIS kernel family executed: all generator convs minus the ResBlocks that ran in the
+        # fused pair kernels (fast mode: stage 3, and the k = 3 ResBlock of stage 2)
+        gemm_flop = VOC_CONV_FLOP_PER_FRAME - (VOC_STAGE3_RB_FLOP_PER_FRAME if pair else 0.0) - (VOC_STAGE2_K3_RB_FLOP_PER_FRAME if pair64 else 0.0)
+        achieved = gemm_flop * f1 / (voc["ms"] * 1e-3) / 1e12
+        voc_ms = voc["ms"] + (pair["ms"] if pair else 0.0) + (pair64["ms"] if pair64 else 0.0)
+        traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
+        tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
+        if os.path.exists(tpath) and not strict and work.mode == "am_vocoder" and B == 32:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        name = ("conv_gemm_x3_kernel (split precision: 3 fp16 MFMAs per algorithmic product; every HiFi-GAN Conv1d/ConvTranspose1d)" if strict else
+                "conv_gemm_kernel<f16> (HiFi-GAN Conv1d/ConvTranspose1d: conv_pre, ups, ResBlocks of stages 0-2 except the fused k=3 one)")
+        roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=PEAK_MFMA_F16, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_MFMA_F16, 4), traffic=traffic,
+                    traffic_note="HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json",
+                    launches=voc["launches"], avg_launch_ms=round(voc["ms"] / voc["launches"], 4),
+                    algorithmic_flop_per_launch=round(gemm_flop * f1 / voc["launches"], 1),
+                    all_vocoder_convs=dict(ms=round(voc_ms, 3), mfma_TFLOPs=round(VOC_CONV_FLOP_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e12, 2),
+                                           hbm_contract_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9, 1),
+                                           hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4)))
+        if strict:
+            roof["mfma_issued_TFLOPs"] = round(3.0 * achieved, 2)      # what the matrix pipes execute: three MFMAs per product
+            roof["mfma_issued_frac"] = round(3.0 * achieved / PEAK_MFMA_F16, 4)
+            roof["note"] = "achieved / frac count ALGORITHMIC FLOPs (one product per multiply-add); the split-precision arithmetic issues 3x that on the fp16 matrix pipes (mfma_issued_*)"
+        if pair:
+            roof["fused_pair_kernel"] = dict(ms=round(pair["ms"], 3), launches=pair["launches"],
+                                             mfma_TFLOPs=round(VOC_STAGE3_RB_FLOP_PER_FRAME * f1 / (pair["ms"] * 1e-3) / 1e12, 2))
+        if pair64:
+            roof["fused_pair_kernel_c64"] = dict(ms=round(pair64["ms"], 3), launches=pair64["launches"],
+                                                 mfma_TFLOPs=round(VOC_STAGE2_K3_RB_FLOP_PER_FRAME * f1 / (pair64["ms"] * 1e-3) / 1e12, 2))
+    if roof is not None and "decoder" in stages and stages["decoder"] > 0:
+        dflop = decoder_flops(f1 / max(B, 1)) * B if work.mode == "am_vocoder" else None
+        if dflop:
+            tf = dflop / (stages["decoder"] * 1e-3) / 1e12
+            roof["mel_decoder"] = dict(ms=round(stages["decoder"], 3), mfma_TFLOPs=round(tf, 2), mfma_frac=round(tf / PEAK_MFMA_F16, 4))
+    return roof, stages, kernels
 
 
 def main():
@@ -65,13 +204,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--mode", default="am_vocoder", choices=["am_vocoder", "ragged", "vocoder"])
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU per (sub-)batch (default: 32 / 256 / 128 by mode)")
+    ap.add_argument("--sub-batches", type=int, default=0, help="am_vocoder: sub-batches per step (default 1 at N = 1, 8 at N > 1 = configs[3])")
     ap.add_argument("--phonemes", type=int, default=256)
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances for the CPU baseline sample (0 = skip)")
     ap.add_argument("--precision", default="fast", choices=["fast", "strict"],
-                    help="frame-rate path: fast = fp16 MFMA operands (BASELINE configs[1]/[4]: bf16 / fp16); strict = split precision "
+                    help="frame-rate path: fast = fp16 MFMA operands (BASELINE configs: bf16 / fp16); strict = split precision "
                          "(3 fp16 MFMAs per product, fp32 activations)")
     ap.add_argument("--decoder-precision", default=None, choices=["f16", "f32", "x3"])
+    ap.add_argument("--no-other-precision", action="store_true", help="skip the extra timed pass in the other precision (N = 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: put every rank on this device (with --backend gloo)")
     args = ap.parse_args()
@@ -84,6 +226,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: emotivoice_amd has no CPU fallback")
     if args.force_device >= 0:
         local_rank = args.force_device
+    if args.sub_batches <= 0:
+        args.sub_batches = 1 if world == 1 else 8
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -98,43 +242,29 @@ def main():
     from emotivoice_amd import _ffi
     from emotivoice_amd.engine import EVEngine
     from emotivoice_amd.sharding import broadcast_blob
-    from emotivoice_amd.synthetic import synth_inputs
 
     # weights: rank 0 packs, everyone receives the blob with one broadcast (RCCL over xGMI), borrowed in place
-    blob_t = broadcast_blob(rank, world, local_rank, dist, dur_mode="bench")
-    eng = EVEngine(device_id=local_rank, precision=args.precision, decoder_precision=args.decoder_precision,
-                   vocoder_chunk_mb=int(os.environ.get("EV_CHUNK_MB", "0")),       # tuning overrides; 0 = engine default
-                   vocoder_streams=int(os.environ.get("EV_VOC_STREAMS", "0")))
-    eng.load_blob_device(blob_t.data_ptr(), blob_t.numel(), keepalive=blob_t)
-
-    B, N = args.batch, args.phonemes
-    utts = synth_inputs(1 + rank, [N] * B, None)
+    dur_mode = "parity" if args.mode == "ragged" else "bench"
+    blob_t = broadcast_blob(rank, world, local_rank, dist, dur_mode=dur_mode)
     dev = torch.device("cuda", local_rank)
-    ling = torch.from_numpy(np.concatenate([u["ling"] for u in utts])).to(dev)
-    cu = np.arange(B + 1, dtype=np.int32) * N
-    spk = torch.zeros(B, dtype=torch.int64, device=dev)
-    style = torch.from_numpy(np.stack([u["style"] for u in utts])).to(dev)
-    content = torch.from_numpy(np.stack([u["content"] for u in utts])).to(dev)
 
-    def step():
-        return eng.synthesize_raw(B, ling.data_ptr(), cu, spk.data_ptr(), style.data_ptr(), content.data_ptr(), 1.0,
-                                  _ffi.EV_FLAG_DEVICE_INPUTS)
+    def make_engine(precision, decoder_precision=None):
+        e = EVEngine(device_id=local_rank, precision=precision, decoder_precision=decoder_precision,
+                     vocoder_chunk_mb=int(os.environ.get("EV_CHUNK_MB", "0")),       # tuning overrides; 0 = engine default
+                     vocoder_streams=int(os.environ.get("EV_VOC_STREAMS", "0")))
+        e.load_blob_device(blob_t.data_ptr(), blob_t.numel(), keepalive=blob_t)
+        return e
+
+    eng = make_engine(args.precision, args.decoder_precision)
+    work = Workload(args, eng, rank, dev, torch, _ffi)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    sync()
-    t0 = time.perf_counter()
-    frames = 0
-    for _ in range(args.steps):
-        res = step()
-        frames += int(res.total_frames)
-    sync()
-    dt = time.perf_counter() - t0
+    frames, dt = timed(work, args.steps, args.warmup, sync)
+    ranks_seen = [0]
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -142,69 +272,43 @@ def main():
         ft = torch.tensor([frames], device=dev, dtype=torch.int64)
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
         frames = int(ft.item())
+        rk = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(rk, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ranks_seen = [int(t.item()) for t in rk]
 
-    # one extra profiled step (hipEvents on the engine's stream around every launch) for the roofline block
-    roof, stages = None, {}
+    roof, stages, kernels, lat, other = None, {}, {}, {}, None
     if rank == 0:
-        eng.set_profiling(True)
-        res = step()
-        torch.cuda.synchronize()
-        stats = {s["name"]: s for s in eng.kernel_stats()}
-        stages = eng.timings()
-        eng.set_profiling(False)
-        f1 = int(res.total_frames)
-        voc = stats.get("voc_conv_gemm_f16") or stats.get("voc_conv_gemm_x3")
-        traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
-        tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
-        if os.path.exists(tpath) and B == 32 and N == 256:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        pair = stats.get("voc_resblock_pair_c32")
-        pair64 = stats.get("voc_resblock_pair_c64")
-        if voc and voc["ms"] > 0:
-            # algorithmic FLOPs of what THIS kernel family executed: all generator convs minus the ResBlocks that ran in the
-            # fused pair kernels (stage 3, and the k = 3 ResBlock of stage 2)
-            gemm_flop = VOC_CONV_FLOP_PER_FRAME - (VOC_STAGE3_RB_FLOP_PER_FRAME if pair else 0.0) - \
-                (VOC_STAGE2_K3_RB_FLOP_PER_FRAME if pair64 else 0.0)
-            achieved = gemm_flop * f1 / (voc["ms"] * 1e-3) / 1e12
-            voc_ms = voc["ms"] + (pair["ms"] if pair else 0.0) + (pair64["ms"] if pair64 else 0.0)
-            roof = dict(bound="mfma", kernel="conv_gemm_kernel<f16> (HiFi-GAN Conv1d/ConvTranspose1d: conv_pre, ups, ResBlocks of stages 0-2 except the fused k=3 one)",
-                        achieved=round(achieved, 2), peak=PEAK_MFMA_F16, unit="TFLOP/s", frac=round(achieved / PEAK_MFMA_F16, 4),
-                        traffic=traffic,
-                        traffic_note="HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json",
-                        launches=voc["launches"], avg_launch_ms=round(voc["ms"] / voc["launches"], 4),
-                        algorithmic_flop_per_launch=round(gemm_flop * f1 / voc["launches"], 1),
-                        all_vocoder_convs=dict(ms=round(voc_ms, 3), mfma_TFLOPs=round(VOC_CONV_FLOP_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e12, 2),
-                                               hbm_contract_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9, 1),
-                                               hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4)))
-            if pair:
-                roof["fused_pair_kernel"] = dict(ms=round(pair["ms"], 3), launches=pair["launches"],
-                                                 mfma_TFLOPs=round(VOC_STAGE3_RB_FLOP_PER_FRAME * f1 / (pair["ms"] * 1e-3) / 1e12, 2))
-            if pair64:
-                roof["fused_pair_kernel_c64"] = dict(ms=round(pair64["ms"], 3), launches=pair64["launches"],
-                                                     mfma_TFLOPs=round(VOC_STAGE2_K3_RB_FLOP_PER_FRAME * f1 / (pair64["ms"] * 1e-3) / 1e12, 2))
-        dec = stats.get("dec_f16_gemm") or stats.get("dec_f32_gemm")
-        if roof is not None and dec and "decoder" in stages:
-            roof["mel_decoder"] = dict(ms=round(stages["decoder"], 3),
-                                       mfma_TFLOPs=round(DEC_FLOP_PER_UTT_1024 * B / (stages["decoder"] * 1e-3) / 1e12, 2),
-                                       mfma_frac=round(DEC_FLOP_PER_UTT_1024 * B / (stages["decoder"] * 1e-3) / 1e12 / PEAK_MFMA_F16, 4))
-        kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in stats.items()}
-    # single-utterance latency (the reference's own call pattern, B = 1; BASELINE configs[0] is 64 phonemes): host-to-host
-    # wall time of one ev_synthesize with host inputs, best of 20
-    lat = {}
-    if rank == 0:
-        for nph in (64, 256):
-            u = synth_inputs(99, [nph], None)[0]
-            ling1 = np.ascontiguousarray(u["ling"]); cu1 = np.array([0, nph], np.int32)
-            spk1 = np.zeros(1, np.int64); st1 = np.ascontiguousarray(u["style"]); ct1 = np.ascontiguousarray(u["content"])
-            best = 1e9
-            for it in range(23):
-                t1 = time.perf_counter()
-                r1 = eng.synthesize_raw(1, ling1.ctypes.data, cu1, spk1.ctypes.data, st1.ctypes.data, ct1.ctypes.data, 1.0, 0)
-                dtl = time.perf_counter() - t1
-                if it >= 3:
-                    best = min(best, dtl)
-            lat["b1_%dph_ms" % nph] = round(best * 1e3, 3)
-            lat["b1_%dph_x_realtime" % nph] = round(int(r1.total_frames) * 256 / 16000 / best, 1)
+        strict = eng.vocoder_precision == "x3"
+        roof, stages, kernels = roofline_block(eng, work, torch, strict)
+        # single-utterance latency (the reference's own call pattern, B = 1; BASELINE configs[0] is 64 phonemes): host-to-host
+        # wall time of one ev_synthesize with host inputs, best of 20
+        if args.mode == "am_vocoder":
+            from emotivoice_amd.synthetic import synth_inputs
+            for nph in (64, 256):
+                u = synth_inputs(99, [nph], None)[0]
+                ling1 = np.ascontiguousarray(u["ling"]); cu1 = np.array([0, nph], np.int32)
+                spk1 = np.zeros(1, np.int64); st1 = np.ascontiguousarray(u["style"]); ct1 = np.ascontiguousarray(u["content"])
+                best = 1e9
+                for it in range(23):
+                    t1 = time.perf_counter()
+                    r1 = eng.synthesize_raw(1, ling1.ctypes.data, cu1, spk1.ctypes.data, st1.ctypes.data, ct1.ctypes.data, 1.0, 0)
+                    dtl = time.perf_counter() - t1
+                    if it >= 3:
+                        best = min(best, dtl)
+                lat["b1_%dph_ms" % nph] = round(best * 1e3, 3)
+                lat["b1_%dph_x_realtime" % nph] = round(int(r1.total_frames) * 256 / 16000 / best, 1)
+        # the same workload in the other precision (one engine at a time: the first one's workspace is released first)
+        if world == 1 and not args.no_other_precision and args.decoder_precision is None:
+            eng.close()
+            op = "strict" if args.precision == "fast" else "fast"
+            eng2 = make_engine(op)
+            work2 = Workload(args, eng2, rank, dev, torch, _ffi)
+            f2, dt2 = timed(work2, max(3, args.steps // 2), 2, lambda: torch.cuda.synchronize())
+            roof2, stages2, _ = roofline_block(eng2, work2, torch, op == "strict")
+            other = dict(precision=op, value=round(f2 / dt2, 1), unit="mel-frames/s", x_realtime=round(f2 / dt2 * 256 / 16000, 1),
+                         ms_per_step=round(dt2 / max(3, args.steps // 2) * 1e3, 3), roofline=roof2,
+                         stage_ms={k: round(v, 3) for k, v in stages2.items()})
+            eng2.close()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -212,22 +316,22 @@ def main():
 
     sr, hop = 16000, 256
     value = frames / dt
+    fast = (eng.decoder_precision, eng.vocoder_precision) == ("f16", "f16")
+    cfg = dict(work.desc)
+    cfg.update(global_batch=work.utts_per_step * world, parallelism="utterance-sharded x%d" % world, precision=args.precision,
+               token_rate_precision="f32 (split fp16x3 GEMMs)", frame_rate_precision="%s/%s" % (eng.decoder_precision, eng.vocoder_precision))
     line = {
         "metric": "mel_frames_per_sec", "value": round(value, 1), "unit": "mel-frames/s",
         "x_realtime": round(value * hop / sr, 1),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if (eng.decoder_precision, eng.vocoder_precision) == ("f16", "f16") else
-                 "decoder %s / vocoder %s (x3 = fp16 hi/lo split, 3 MFMAs per product, fp32 activations)" % (eng.decoder_precision, eng.vocoder_precision),
-        "data": "synthetic",
-        "config": {"workload": "configs[1]: batch=%d x %d-phoneme synthetic utterances per GPU, 1 speaker, AM+vocoder end-to-end, "
-                               "4 frames/phoneme" % (B, N), "global_batch": B * world, "phonemes": N,
-                   "frames_per_utt": int(frames / args.steps / world / B), "parallelism": "utterance-sharded x%d" % world,
-                   "token_rate_precision": "f32", "frame_rate_precision": "%s/%s" % (eng.decoder_precision, eng.vocoder_precision)},
+        "dtype": "f16" if fast else "f16x3 (fp16 hi/lo split, 3 MFMAs per product, fp32 activations)",
+        "data": "synthetic", "ranks_seen": ranks_seen, "config": cfg,
         "latency": lat, "roofline": roof, "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "kernels_ms": kernels,
+        "other_precision": other,
     }
     if world == 1 and args.cpu_utts > 0:
-        line["cpu_baseline"] = cpu_baseline(args.cpu_utts, N)
+        line["cpu_baseline"] = cpu_baseline(args.cpu_utts, args.phonemes)
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))

@@ -836,6 +836,227 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-precision conv-GEMM, second generation: the kernel of the EV_PREC_X3 frame-rate path (mel decoder GEMMs and every
+// HiFi-GAN conv in "strict" mode) and of the token-rate path.  Same arithmetic as conv_gemm_split_kernel above (which stays as
+// the A/B reference, EV_X3_OLD=1), restructured for the MFMA-bound regime that three MFMAs per product create:
+//   * 512 threads = 8 waves on one CU (2 per SIMD), tile 256 rows x BN, wave tile (256 / WM) x (BN / WN): with BN = 128 a wave
+//     owns 64 x 64 outputs = 16 accumulator tiles x 2 (hi*hi and the 2^11-scaled cross terms) = 128 accumulator registers,
+//     and a (K-chunk, tap) step is 48 MFMAs per wave against 16 fragment reads (3 MFMAs per ds_read_b128; the fp16 kernel's
+//     256 x 128 tile has 2.7);
+//   * the pipeline of the fp16 kernel: the fp32 activation slab of K-chunk kc+1 is requested at the first tap of chunk kc and
+//     split into its hi / lo fp16 planes when it is written to LDS at the last tap; the weight tiles (hi and lo planes) of
+//     step s+2 are requested while step s computes and written one step later; static A/B register parity, branch-free
+//     steady state, one barrier per step;
+//   * leaky-relu of the consumer side (models/hifigan/models.py:51,118) is applied to the fp32 value while staging, before
+//     the split; epilogues are the straight-line LDS-transposed ones of the fp16 kernel.
+// LDS: 2 buffers x 2 planes x (384 x 64 B) for the slab (the last 64 rows only pad the chunk count to 3 per thread) +
+// 2 x 2 x (BN x 64 B) for the weights = 128 KB at BN = 128: one block per CU.
+template <int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const ConvGemmParams p) {
+    constexpr int BM = 256;
+    constexpr int TT = BM / WM, TC = BN / WN, MT = TT / 16, NT = TC / 16;
+    constexpr int SLABR = 384, XCH = 3;                 // staged rows (>= BM + MAX_SPAN), 32-byte source chunks per thread
+    constexpr int XBUF = SLABR * 64, WBUF = BN * 64;
+    static_assert(WM * WN == 8 && SLABR * 4 == XCH * 512 && SLABR >= BM + MAX_SPAN, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xh = smem;                    // [2][SLABR][64]  hi parts
+    char* Xl = Xh + 2 * XBUF;           // [2][SLABR][64]  lo parts (scaled by 2^11)
+    char* Wh = Xl + 2 * XBUF;           // [2][BN][64]
+    char* Wl = Wh + 2 * WBUF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave / WN, wc = wave % WN;
+    const int nN = p.N / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (bid / nN) * BM, n0 = (bid % nN) * BN;
+    const int taps = p.taps, nkc = p.K >> 5, steps = nkc * taps;
+    const long a_pitch = (long)p.lda * 4;
+    const long w_tap_pitch = (long)p.K * 2, w_row_pitch = w_tap_pitch * taps;
+
+    // slab staging: chunk c -> slab row c >> 2, 16-byte fp16 part c & 3  <-  32 bytes (8 floats) of the fp32 row.  Rows beyond
+    // the conv's real span re-read the last needed row (cache hits, exact chunk counts, no predicates)
+    const char* xsrc[XCH]; int xdst[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + i * 512, r = c >> 2, part = c & 3;
+        const int rs = min(r, BM + (p.taps - 1) * p.dil - 1);
+        xsrc[i] = reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil + rs) * a_pitch + part * 32;
+        xdst[i] = swz(r, part);
+    }
+    const int wr_ = (tid >> 2) % BN, wp_ = tid & 3;          // BN < 128: the upper threads duplicate chunks of the lower ones
+    const char* const whg = reinterpret_cast<const char*>(p.W) + (long)(n0 + wr_) * w_row_pitch + wp_ * 16;
+    const char* const wlg = reinterpret_cast<const char*>(p.W_lo) + (long)(n0 + wr_) * w_row_pitch + wp_ * 16;
+    const int wdst = swz(wr_, wp_);
+    const bool pro = p.pro_lrelu != 0;
+    const float pro_slope = p.pro_slope;
+
+    float4 xa0, xb0, xa1, xb1, xa2, xb2;                     // 3 chunks x 8 floats (scalars: arrays behind macros end up in scratch)
+    uint4 whA, wlA, whB, wlB;
+#define EV_X_GLOAD_X(KC)                                                                         \
+    {                                                                                            \
+        xa0 = *reinterpret_cast<const float4*>(xsrc[0] + (long)(KC) * 128);                      \
+        xb0 = *reinterpret_cast<const float4*>(xsrc[0] + (long)(KC) * 128 + 16);                 \
+        xa1 = *reinterpret_cast<const float4*>(xsrc[1] + (long)(KC) * 128);                      \
+        xb1 = *reinterpret_cast<const float4*>(xsrc[1] + (long)(KC) * 128 + 16);                 \
+        xa2 = *reinterpret_cast<const float4*>(xsrc[2] + (long)(KC) * 128);                      \
+        xb2 = *reinterpret_cast<const float4*>(xsrc[2] + (long)(KC) * 128 + 16);                 \
+    }
+#define EV_X_SPLIT_STORE(XA, XB, DST, BUF)                                                       \
+    {                                                                                            \
+        float f_[8] = {XA.x, XA.y, XA.z, XA.w, XB.x, XB.y, XB.z, XB.w};                          \
+        if (pro) {                                                                               \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) f_[e] = fmaxf(f_[e], f_[e] * pro_slope); \
+        }                                                                                        \
+        half8 hi_, lo_;                                                                          \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                          \
+            const _Float16 h_ = (_Float16)f_[e];                                                 \
+            hi_[e] = h_;                                                                         \
+            lo_[e] = (_Float16)((f_[e] - (float)h_) * 2048.0f);                                  \
+        }                                                                                        \
+        *reinterpret_cast<half8*>(Xh + (BUF) * XBUF + (DST)) = hi_;                              \
+        *reinterpret_cast<half8*>(Xl + (BUF) * XBUF + (DST)) = lo_;                              \
+    }
+#define EV_X_SSTORE_X(BUF)                                                                       \
+    {                                                                                            \
+        EV_X_SPLIT_STORE(xa0, xb0, xdst[0], BUF)                                                 \
+        EV_X_SPLIT_STORE(xa1, xb1, xdst[1], BUF)                                                 \
+        EV_X_SPLIT_STORE(xa2, xb2, xdst[2], BUF)                                                 \
+    }
+#define EV_X_GLOAD_W(DST, KC, TAP)                                                               \
+    {                                                                                            \
+        const long o_ = (long)(TAP) * w_tap_pitch + (long)(KC) * 64;                             \
+        wh##DST = *reinterpret_cast<const uint4*>(whg + o_);                                     \
+        wl##DST = *reinterpret_cast<const uint4*>(wlg + o_);                                     \
+    }
+#define EV_X_SSTORE_W(SRC, BUF)                                                                  \
+    {                                                                                            \
+        *reinterpret_cast<uint4*>(Wh + (BUF) * WBUF + wdst) = wh##SRC;                           \
+        *reinterpret_cast<uint4*>(Wl + (BUF) * WBUF + wdst) = wl##SRC;                           \
+    }
+
+    f32x4 acc[NT][MT], accl[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) { acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int fr = lane & 15, fq = lane >> 4;
+    int woff[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) woff[a] = swz(wc * TC + a * 16 + fr, fq);
+
+#define EV_X_COMPUTE(WSEL, KC, TAP)                                                                            \
+    {                                                                                                          \
+        const int row0_ = wt * TT + fr + (TAP) * p.dil;                                                        \
+        const int xo_ = ((KC) & 1) * XBUF + row0_ * 64 + ((fq ^ ((row0_ >> 1) & 3)) << 4);                      \
+        uint4 wh_[NT], wl_[NT];                                                                                \
+        _Pragma("unroll") for (int a = 0; a < NT; ++a) {                                                       \
+            wh_[a] = *reinterpret_cast<const uint4*>(Wh + (WSEL) * WBUF + woff[a]);                            \
+            wl_[a] = *reinterpret_cast<const uint4*>(Wl + (WSEL) * WBUF + woff[a]);                            \
+        }                                                                                                      \
+        _Pragma("unroll") for (int b = 0; b < MT; ++b) {                                                       \
+            const uint4 xh_ = *reinterpret_cast<const uint4*>(Xh + xo_ + b * 16 * 64);                         \
+            const uint4 xl_ = *reinterpret_cast<const uint4*>(Xl + xo_ + b * 16 * 64);                         \
+            _Pragma("unroll") for (int a = 0; a < NT; ++a) {                                                   \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&wh_[a]), *reinterpret_cast<const half8*>(&xh_), acc[a][b], 0, 0, 0);   \
+                accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&wh_[a]), *reinterpret_cast<const half8*>(&xl_), accl[a][b], 0, 0, 0); \
+                accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&wl_[a]), *reinterpret_cast<const half8*>(&xh_), accl[a][b], 0, 0, 0); \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    // prologue: X(0), W(step 0) -> LDS; W(step 1) -> registers
+    EV_X_GLOAD_X(0)
+    EV_X_GLOAD_W(A, 0, 0)
+    EV_X_SSTORE_X(0)
+    EV_X_SSTORE_W(A, 0)
+    {
+        const int k1 = (taps > 1) ? 0 : (nkc > 1 ? 1 : 0), t1 = (taps > 1) ? 1 : 0;
+        EV_X_GLOAD_W(B, k1, t1)
+    }
+    __syncthreads();
+
+    int wsel = 0, kc = 0, tap = 0;
+    // One pipeline step (see conv_gemm_kernel): LD receives W(s+2), ST holds W(s+1) and is written to the idle LDS buffer.
+#define EV_X_STEP(LD, ST)                                                                  \
+    {                                                                                      \
+        const bool more_ = kc + 1 < nkc;                                                   \
+        int t2_ = tap + 2, k2_ = kc;                                                       \
+        if (t2_ >= taps) { t2_ -= taps; k2_ = kc + 1; }                                    \
+        if (t2_ >= taps) { t2_ -= taps; k2_ += 1; }                                        \
+        if (k2_ >= nkc) { k2_ = kc; t2_ = tap; }                                           \
+        EV_X_GLOAD_W(LD, k2_, t2_)                                                         \
+        if (tap == 0 && more_) { EV_X_GLOAD_X(kc + 1) }                                    \
+        EV_X_COMPUTE(wsel, kc, tap)                                                        \
+        EV_X_SSTORE_W(ST, wsel ^ 1)                                                        \
+        if (tap == taps - 1) {                                                             \
+            if (more_) { EV_X_SSTORE_X((kc + 1) & 1) }                                     \
+            tap = 0; ++kc;                                                                 \
+        } else {                                                                           \
+            ++tap;                                                                         \
+        }                                                                                  \
+        __syncthreads();                                                                   \
+        wsel ^= 1;                                                                         \
+    }
+    int s = 0;
+    for (; s + 1 < steps; s += 2) {
+        EV_X_STEP(A, B)
+        EV_X_STEP(B, A)
+    }
+    if (s < steps) EV_X_STEP(A, B)
+#undef EV_X_STEP
+#undef EV_X_COMPUTE
+#undef EV_X_GLOAD_X
+#undef EV_X_SPLIT_STORE
+#undef EV_X_SSTORE_X
+#undef EV_X_GLOAD_W
+#undef EV_X_SSTORE_W
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] += accl[a][b] * (1.0f / 2048.0f);
+    if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+    else gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+}
+
+template <int BN>
+static constexpr size_t x3_lds_bytes() { return 4 * (size_t)384 * 64 + 4 * (size_t)BN * 64; }
+
+template <int BN, int WM, int WN, int EPI>
+static void launch_x3_cfg(const ConvGemmParams& p, hipStream_t s) {
+    static_assert(8 * 32 * ((BN / WN) * 4 + 16) <= x3_lds_bytes<BN>(), "epilogue scratch aliases the staging buffers");
+    const int grid = (p.M / 256) * (p.N / BN);
+    hipLaunchKernelGGL((conv_gemm_x3_kernel<BN, WM, WN, EPI>), dim3(grid), dim3(512), x3_lds_bytes<BN>(), s, p);
+}
+template <int EPI>
+static void launch_x3_epi(const ConvGemmParams& p, hipStream_t s) {
+    if (p.N % 128 == 0) launch_x3_cfg<128, 4, 2, EPI>(p, s);
+    else if (p.N % 64 == 0) launch_x3_cfg<64, 8, 1, EPI>(p, s);
+    else launch_x3_cfg<32, 8, 1, EPI>(p, s);
+}
+// large-LDS opt-in of every instantiation launch_x3 can reach (called per device from init_device_kernels)
+template <int EPI>
+static hipError_t x3_attr_epi() {
+    hipError_t e = hipSuccess, r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<128, 4, 2, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<128>()); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<64, 8, 1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<64>()); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<32, 8, 1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<32>()); if (r != hipSuccess) e = r;
+    return e;
+}
+static hipError_t x3_set_attributes() {
+    hipError_t e = hipSuccess, r;
+    r = x3_attr_epi<EPI_O32>(); if (r != hipSuccess) e = r;
+    r = x3_attr_epi<EPI_RARE_ACT | EPI_O32>(); if (r != hipSuccess) e = r;
+    r = x3_attr_epi<EPI_RES32 | EPI_O32>(); if (r != hipSuccess) e = r;
+    r = x3_attr_epi<EPI_RES32 | EPI_ACC32 | EPI_O32>(); if (r != hipSuccess) e = r;
+    r = x3_attr_epi<EPI_GENERIC>(); if (r != hipSuccess) e = r;
+    return e;
+}
+
 template <int BN, int EPI>
 static void launch_split_bn(const ConvGemmParams& p, hipStream_t s) {
     constexpr int BM = 128;
@@ -853,15 +1074,26 @@ static void launch_split_epi(const ConvGemmParams& p, hipStream_t s) {
 }
 
 static void launch_split(const ConvGemmParams& p, hipStream_t s) {
-    // the token-rate GEMMs write fp32 only: plain / fp32 residual / relu-gelu (exact erff: fp32 output) use the straight-line
-    // epilogue, the per-utterance bias of embed_projection1 (and anything else) the generic one
+    // split-precision GEMMs write fp32 only: plain / leaky-relu / fp32 residual (+ fp32 accumulate-in) / relu-gelu (exact erff:
+    // fp32 output) use the straight-line epilogue, the per-utterance bias of embed_projection1 (and anything else) the generic one
+    static const bool old_kernel = getenv("EV_X3_OLD") != nullptr;       // A/B switch: first-generation 128 x 64 kernel
+    static const bool force_generic = getenv("EV_EPI_GENERIC") != nullptr;
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
+    const bool odd_slope = p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f);       // max(v, s v) form needs s in [0, 1]
     const bool o32 = p.out32 && !p.out16 && !p.out32_before_post && !p.post_lrelu;
-    const bool plain = !p.seq_bias && !p.acc32 && !p.add16_a && o32 && p.act != ACT_LRELU && !getenv("EV_EPI_GENERIC");
-    if (plain && !p.res && !rare_act) return launch_split_epi<EPI_O32>(p, s);
-    if (plain && !p.res && rare_act) return launch_split_epi<EPI_RARE_ACT | EPI_O32>(p, s);
-    if (plain && p.res && p.res_dtype == DT_F32 && !rare_act) return launch_split_epi<EPI_RES32 | EPI_O32>(p, s);
-    launch_split_epi<EPI_GENERIC>(p, s);
+    const bool plain = !p.seq_bias && !p.add16_a && o32 && !odd_slope && !force_generic;
+    const bool res32 = p.res && p.res_dtype == DT_F32;
+    if (old_kernel) {
+        if (plain && !p.acc32 && p.act != ACT_LRELU && !p.res && !rare_act) return launch_split_epi<EPI_O32>(p, s);
+        if (plain && !p.acc32 && p.act != ACT_LRELU && !p.res && rare_act) return launch_split_epi<EPI_RARE_ACT | EPI_O32>(p, s);
+        if (plain && !p.acc32 && p.act != ACT_LRELU && res32 && !rare_act) return launch_split_epi<EPI_RES32 | EPI_O32>(p, s);
+        return launch_split_epi<EPI_GENERIC>(p, s);
+    }
+    if (plain && !p.acc32 && !p.res && !rare_act) return launch_x3_epi<EPI_O32>(p, s);
+    if (plain && !p.acc32 && !p.res && rare_act) return launch_x3_epi<EPI_RARE_ACT | EPI_O32>(p, s);
+    if (plain && !p.acc32 && res32 && !rare_act) return launch_x3_epi<EPI_RES32 | EPI_O32>(p, s);
+    if (plain && p.acc32 && res32 && !rare_act) return launch_x3_epi<EPI_RES32 | EPI_ACC32 | EPI_O32>(p, s);
+    launch_x3_epi<EPI_GENERIC>(p, s);
 }
 
 // =====================================================================================================================
@@ -1471,6 +1703,7 @@ int init_device_kernels(int device) {
     attr((const void*)resblock_pair_c64_kernel<3, 0>, PAIR64_LDS_BYTES);
     attr((const void*)resblock_pair_c64_kernel<3, 1>, PAIR64_LDS_BYTES);
     attr((const void*)resblock_pair_c64_kernel<3, 2>, PAIR64_LDS_BYTES);
+    if (x3_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     g_dev_ready[device] = (e == hipSuccess);
     return e == hipSuccess ? 0 : -1;
 }

@@ -6,7 +6,7 @@ durations / mel lengths bit-exact.  Stage taps of the fp32 token-rate path are h
 
 Two precisions of the frame-rate path are tested (include/evhip.h, EV_PREC_*):
   * "strict" (decoder + generator in split precision, fp32 activations): every output and every Appendix-C tap is held to
-    TOL_STRICT = 1e-4 (measured ~1e-5) -- two orders inside the contract, also on the DC-free fixture;
+    TOL_STRICT = 2e-5 (measured <= 3.1e-6) -- fifty times inside the contract, also on the DC-free fixture;
   * "fast" (fp16 MFMA operands, the precision BASELINE.json's bf16 / fp16 configs name): mel and waveform <= 1e-3 on the
     synthetic-weight fixtures, whose waveform carries a DC offset ~3x its AC amplitude.  On a zero-mean waveform
     (tests/golden/n28_zero_dc.npz) fp16 operands measure ~2.2e-3: tools/precision_study.py attributes that evenly to the ~150
@@ -29,7 +29,7 @@ torch = pytest.importorskip("torch")
 
 TOL_OUT = 1e-3          # north_star tolerance for mel and waveform
 TOL_F32_TAP = 1e-4      # fp32 token-rate taps
-TOL_STRICT = 1e-4       # every frame-rate quantity in the split-precision mode
+TOL_STRICT = 2e-5       # every frame-rate quantity in the split-precision mode (measured <= 3.1e-6 over all tests)
 FAST_ZDC = 3e-3         # fp16 operands on a zero-mean waveform (measured 2.2e-3; see module docstring)
 NEAR_EPS = 2e-5         # |frac(exp(log_d) - 1) - 0.5| below which a duration may legitimately flip (log_d agrees to ~1e-6)
 REPORT = {}
