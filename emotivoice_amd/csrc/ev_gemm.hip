@@ -1083,7 +1083,11 @@ static void launch_split(const ConvGemmParams& p, hipStream_t s) {
     const bool o32 = p.out32 && !p.out16 && !p.out32_before_post && !p.post_lrelu;
     const bool plain = !p.seq_bias && !p.add16_a && o32 && !odd_slope && !force_generic;
     const bool res32 = p.res && p.res_dtype == DT_F32;
-    if (old_kernel) {
+    // few tiles (the token-rate GEMMs: 33 x 3..12 tiles of 256 x 128 at 32 x 256 tokens) cannot fill 256 CUs with one 8-wave block
+    // each: the first-generation kernel's 128 x 64 tiles at two 4-wave blocks per CU give 4x the blocks (measured: encoder GEMMs
+    // 1.40 ms vs 1.81 ms, predictors 0.31 vs 0.54 ms)
+    const long tiles_x3 = (long)(p.M / 256) * (p.N % 128 == 0 ? p.N / 128 : (p.N % 64 == 0 ? p.N / 64 : p.N / 32));
+    if (old_kernel || (tiles_x3 < 512 && p.N % 64 == 0)) {
         if (plain && !p.acc32 && p.act != ACT_LRELU && !p.res && !rare_act) return launch_split_epi<EPI_O32>(p, s);
         if (plain && !p.acc32 && p.act != ACT_LRELU && !p.res && rare_act) return launch_split_epi<EPI_RARE_ACT | EPI_O32>(p, s);
         if (plain && !p.acc32 && p.act != ACT_LRELU && res32 && !rare_act) return launch_split_epi<EPI_RES32 | EPI_O32>(p, s);

@@ -30,16 +30,26 @@ class _DevArray:
 
 
 class JETSGeneratorHIP:
-    def __init__(self, config=None, decoder_precision: str = "f16", keep_stages: bool = False, pe_len: int = 4096):
+    def __init__(self, config=None, decoder_precision: Optional[str] = None, keep_stages: bool = False, pe_len: int = 4096,
+                 precision: Optional[str] = None, vocoder_precision: Optional[str] = None):
+        """``precision``: "fast" (fp16 MFMA operands on the frame-rate path) or "strict" (split precision, fp32-class parity with
+        the reference module: ~1e-6 relative L2 on mel and waveform); default "fast".  See engine.resolve_precision."""
         self.config = config
         self.shapes: EVShapes = from_reference_config(config)
         self.segment_size = self.shapes.segment_size
         self.upsample_factor = self.shapes.upsample_factor
-        self._prec, self._keep, self._pe_len = decoder_precision, keep_stages, pe_len
+        self._precision, self._dec_prec, self._voc_prec = precision, decoder_precision, vocoder_precision
+        self._keep, self._pe_len = keep_stages, pe_len
         self._device_id: Optional[int] = None
         self._engine: Optional[EVEngine] = None
         self._blob = None
+        self._stream_ptr = 0            # 0 = the engine's own stream
         self.training = False
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
 
     # ---- nn.Module-like surface used by the reference callers
     def to(self, device):
@@ -70,7 +80,9 @@ class JETSGeneratorHIP:
 
     def _ensure_engine(self):
         if self._engine is None:
-            self._engine = EVEngine(self.shapes, self._device_id or 0, self._prec, self._keep)
+            self._engine = EVEngine(self.shapes, self._device_id or 0, decoder_precision=self._dec_prec, keep_stages=self._keep,
+                                    vocoder_precision=self._voc_prec, precision=self._precision)
+            self._stream_ptr = 0
             if self._blob is not None:
                 self._engine.load_blob(*self._blob)
         return self._engine
@@ -108,6 +120,11 @@ class JETSGeneratorHIP:
             raise EVError("call .to('cuda:N') first: there is no CPU path")
         eng = self._ensure_engine()
         is_torch = hasattr(inputs_ling, "detach")
+        if is_torch and inputs_ling.is_cuda:
+            return self._forward_device(eng, inputs_ling, input_lengths, inputs_speaker, inputs_style_embedding, inputs_content_embedding)
+        if self._stream_ptr:
+            eng.set_stream(0)
+            self._stream_ptr = 0
 
         def host(x, dt):
             if hasattr(x, "detach"):
@@ -141,8 +158,54 @@ class JETSGeneratorHIP:
         up = self.upsample_factor
         if is_torch:
             out = self._gather_torch(eng, res, B, Nmax, lengths, cu, T, offs, up)
+            # host inputs run on the engine's own stream; the copies above were queued on torch's current stream and read the
+            # handle's arena, which the next call may overwrite: finish them before returning
+            import torch
+            torch.cuda.current_stream(torch.device("cuda", self._device_id)).synchronize()
         else:
             out = self._gather_numpy(eng, res, B, Nmax, lengths, cu, T, offs, up)
+        out.update(mel_targets=None, postnet_outputs=None, pitch_targets=None, energy_targets=None, duration_targets=None,
+                   input_lengths=input_lengths, output_lengths=None, log_p_attn=None, bin_loss=None, z_start_idxs=None,
+                   segment_size=self.segment_size)
+        return out
+
+    def _forward_device(self, eng, inputs_ling, input_lengths, inputs_speaker, inputs_style_embedding, inputs_content_embedding):
+        """The reference's own call pattern (inference_am_vocoder_joint.py:115-129): every input already a CUDA tensor.  Nothing
+        is staged through the host: the engine runs on torch's CURRENT stream (ev_set_stream) and reads the tensors in place
+        (EV_FLAG_DEVICE_INPUTS); the outputs are cloned on the same stream, so ordering against later torch work is the
+        stream's.  One small device -> host copy remains, the lengths (the reference synchronises too, alignment.py:195).
+        Ids are not range-checked on this path (that would be a second sync): the kernels clamp them to the tables."""
+        import torch
+        dev = inputs_ling.device
+        if dev.index is not None and self._device_id is not None and dev.index != self._device_id:
+            raise EVError("inputs live on cuda:%d, the generator on cuda:%d" % (dev.index, self._device_id))
+        stream = torch.cuda.current_stream(dev)
+        if stream.cuda_stream != self._stream_ptr:
+            eng.set_stream(stream.cuda_stream)
+            self._stream_ptr = stream.cuda_stream
+        ling = inputs_ling.long()
+        if ling.dim() == 1:
+            ling = ling[None]
+        B, Nmax = ling.shape
+        lengths = (input_lengths.detach().reshape(-1).to("cpu") if hasattr(input_lengths, "detach")
+                   else torch.as_tensor(np.asarray(input_lengths)).reshape(-1)).to(torch.int64).numpy()
+        if lengths.shape[0] != B or lengths.max() > Nmax or lengths.min() <= 0:
+            raise ValueError("input_lengths inconsistent with inputs_ling")
+        if B == 1 and int(lengths[0]) == Nmax:
+            packed = ling.reshape(-1).contiguous()
+        else:
+            packed = torch.cat([ling[b, :int(lengths[b])] for b in range(B)]).contiguous()
+        as_dev = lambda x, dt: (x if hasattr(x, "detach") else torch.as_tensor(np.asarray(x))).to(dev, dt)   # noqa: E731
+        spk = as_dev(inputs_speaker, torch.int64).reshape(-1).contiguous()
+        style = as_dev(inputs_style_embedding, torch.float32).reshape(B, -1).contiguous()
+        content = as_dev(inputs_content_embedding, torch.float32).reshape(B, -1).contiguous()
+        cu = np.zeros(B + 1, np.int32)
+        cu[1:] = np.cumsum(lengths)
+        res = eng.synthesize_raw(B, packed.data_ptr(), cu, spk.data_ptr(), style.data_ptr(), content.data_ptr(), 1.0,
+                                 _ffi.EV_FLAG_DEVICE_INPUTS)
+        T = np.array([res.mel_lens[b] for b in range(B)], np.int64)
+        offs = np.array([res.mel_offsets[b] for b in range(B + 1)], np.int64)
+        out = self._gather_torch(eng, res, B, Nmax, lengths, cu, T, offs, self.upsample_factor)
         out.update(mel_targets=None, postnet_outputs=None, pitch_targets=None, energy_targets=None, duration_targets=None,
                    input_lengths=input_lengths, output_lengths=None, log_p_attn=None, bin_loss=None, z_start_idxs=None,
                    segment_size=self.segment_size)

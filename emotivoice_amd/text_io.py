@@ -18,8 +18,10 @@ class InputLine(NamedTuple):
 
 
 def read_table(path: str) -> Dict[str, int]:
-    with open(path, "r") as f:
-        return {line.rstrip("\n"): i for i, line in enumerate(f.readlines())}
+    """token / speaker -> id by line index, keys stripped like the reference's ``t.strip()`` (inference_am_vocoder_joint.py:76-80;
+    the speaker file is read as utf-8 there, and the token file is ASCII)."""
+    with open(path, "r", encoding="utf-8") as f:
+        return {line.strip(): i for i, line in enumerate(f.readlines())}
 
 
 def parse_line(line: str) -> InputLine:
@@ -30,7 +32,7 @@ def parse_line(line: str) -> InputLine:
 
 
 def read_text_file(path: str) -> List[InputLine]:
-    with open(path, "r") as f:
+    with open(path, "r", encoding="utf-8") as f:
         return [parse_line(l) for l in f if l.strip()]
 
 

@@ -38,6 +38,23 @@ SHAPES = {
     "dec_ffn1": (0, RF, 384, 1536, 3, 1, False, False),
     "dec_ffn1_gelu": (0, RF, 384, 1536, 3, 1, False, "gelu"),
     "dec_ffn2": (0, RF, 1536, 384, 3, 1, True, False),
+    # split precision (dtype 2: fp32 activations, fp16 hi/lo weights, 3 MFMAs per product)
+    "x3_s0_k3": (2, RF * 8, 256, 256, 3, 1, False, True),
+    "x3_s0_k11": (2, RF * 8, 256, 256, 11, 5, False, True),
+    "x3_s1_k3": (2, RF * 64, 128, 128, 3, 1, False, True),
+    "x3_s1_k7": (2, RF * 64, 128, 128, 7, 3, False, True),
+    "x3_s1_k11": (2, RF * 64, 128, 128, 11, 5, False, True),
+    "x3_s1_k11_res": (2, RF * 64, 128, 128, 11, 1, True, False),
+    "x3_s2_k3": (2, RF * 128, 64, 64, 3, 1, False, True),
+    "x3_s2_k11": (2, RF * 128, 64, 64, 11, 5, False, True),
+    "x3_s3_k3": (2, RF * 256, 32, 32, 3, 1, False, True),
+    "x3_s3_k11": (2, RF * 256, 32, 32, 11, 5, False, True),
+    "x3_up0": (2, RF, 512, 2048, 3, 1, False, True),
+    "x3_up1": (2, RF * 8, 256, 1024, 3, 1, False, True),
+    "x3_dec_qkv": (2, RF, 384, 1152, 1, 1, False, False),
+    "x3_dec_ffn1_gelu": (2, RF, 384, 1536, 3, 1, False, "gelu"),
+    "x3_dec_ffn2": (2, RF, 1536, 384, 3, 1, True, False),
+    "x3_enc_ffn1": (2, 8448, 384, 1536, 3, 1, False, "gelu"),
     "enc_ffn1_f32": (1, 8448, 384, 1536, 3, 1, False, False),
     "enc_ffn2_f32": (1, 8448, 1536, 384, 3, 1, True, False),
 }
@@ -54,13 +71,17 @@ def main():
         tdt = torch.float16 if dtype == 0 else torch.float32
         es = 2 if dtype == 0 else 4
         a = torch.randn(M + 128, K, device="cuda", dtype=torch.float32).to(tdt)
-        w = (torch.randn(N, taps, K, device="cuda") / (K * taps) ** 0.5).to(tdt)
+        w = (torch.randn(N, taps, K, device="cuda") / (K * taps) ** 0.5)
+        w_lo = ((w - w.half().float()) * 2048.0).half() if dtype == 2 else None
+        w = w.half() if dtype == 2 else w.to(tdt)
         bias = torch.randn(N, device="cuda")
         r = torch.randn(M, N, device="cuda").to(torch.float16 if dtype == 0 else torch.float32) if res else None
         out = torch.empty(M, N, device="cuda", dtype=torch.float16 if dtype == 0 else torch.float32)
         d = _ffi.ev_conv_gemm_desc()
         d.dtype = dtype
         d.A, d.lda, d.W, d.bias = a[64:].data_ptr(), K, w.data_ptr(), bias.data_ptr()
+        if w_lo is not None:
+            d.W_lo = w_lo.data_ptr()
         d.M, d.N, d.K, d.taps, d.dil, d.center = M, N, K, taps, dil, (taps - 1) // 2
         d.out_scale = 1.0
         if pro == "gelu":
@@ -68,7 +89,7 @@ def main():
         elif pro:
             d.pro_lrelu, d.pro_slope, d.act, d.act_slope = 1, 0.1, 3, 0.1
         if r is not None:
-            d.res, d.res_dtype, d.ldres = r.data_ptr(), dtype, N
+            d.res, d.res_dtype, d.ldres = r.data_ptr(), (0 if dtype == 0 else 1), N
         if dtype == 0:
             d.out16 = out.data_ptr()
         else:
