@@ -39,6 +39,12 @@ class ev_result(C.Structure):
     ]
 
 
+class ev_bert_config(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32),
+                ("intermediate", C.c_int32), ("max_position", C.c_int32), ("type_vocab", C.c_int32), ("ln_eps", C.c_float),
+                ("reserved", C.c_int32 * 8)]
+
+
 class ev_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -82,6 +88,9 @@ SIGNATURES = {
     "ev_kernel_stat_count": (C.c_int, [_P]),
     "ev_get_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(ev_kernel_stat)]),
     "ev_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "ev_default_bert_config": (None, [C.POINTER(ev_bert_config)]),
+    "ev_style_load_weights": (C.c_int, [_P, C.POINTER(ev_bert_config), _P, C.c_size_t]),
+    "ev_style_embed": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_uint32, _P]),
     "ev_op_conv_gemm": (C.c_int, [C.POINTER(ev_conv_gemm_desc), _P]),
     "ev_op_resblock_pair_c32": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_resblock_pair_c64": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),

@@ -64,8 +64,10 @@ struct ev_handle {
     std::map<std::string, WeightEntry> wt;
     std::map<std::string, float> scalar_cache;
     float* pe_dev = nullptr; int pe_cap = 0;     // positional table, extended on demand beyond the packed length   // host copies of 1-element tensors (biases of the Linear(C,1) heads, PE alphas)
+    // SimBERT style encoder (ev_style_load_weights / ev_style_embed): its own blob, merged into `wt` under the "sb." prefix
+    char* sblob = nullptr; size_t sbytes = 0; ev_bert_config bcfg{}; bool style_loaded = false;
     // arena
-    char* arena[2] = {nullptr, nullptr}; size_t arena_bytes[2] = {0, 0};   // [0] token-rate phase, [1] frame-rate phase + vocoder
+    char* arena[3] = {nullptr, nullptr, nullptr}; size_t arena_bytes[3] = {0, 0, 0};   // [0] token-rate phase, [1] frame-rate phase + vocoder, [2] SimBERT
     char* pinned = nullptr; size_t pinned_bytes = 0;
     // persistent outputs (host side)
     std::vector<int32_t> mel_lens; std::vector<int64_t> mel_offs;
@@ -115,23 +117,32 @@ int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 // count x { char name[64]; u32 dtype(0 f16,1 f32,2 i32,3 i64); u32 ndim; u64 dims[4]; u64 offset; u64 nbytes } | data (256-B aligned)
 struct BlobEntry { char name[64]; uint32_t dtype, ndim; uint64_t dims[4]; uint64_t offset, nbytes; };
 
-int parse_blob(ev_handle* h, const char* host_hdr, size_t nbytes) {
+// `style` selects which of the two blobs is being (re)loaded: the generator's (every name without the "sb." prefix) or the
+// SimBERT encoder's ("sb." names); the other one's entries stay in the table.
+int parse_blob(ev_handle* h, const char* host_hdr, size_t nbytes, bool style = false) {
     if (nbytes < 16 || memcmp(host_hdr, "EVW1", 4) != 0) return fail(h, "weight blob: bad magic");
     uint32_t count;
     memcpy(&count, host_hdr + 8, 4);
     if (16 + (size_t)count * sizeof(BlobEntry) > nbytes) return fail(h, "weight blob: truncated table");
-    h->wt.clear();
+    for (auto it = h->wt.begin(); it != h->wt.end();) {
+        const bool is_style = it->first.compare(0, 3, "sb.") == 0;
+        if (is_style == style) it = h->wt.erase(it); else ++it;
+    }
     h->scalar_cache.clear();
-    if (h->pe_dev) { (void)hipFree(h->pe_dev); h->pe_dev = nullptr; }
-    h->pe_cap = 0;
+    if (!style) {
+        if (h->pe_dev) { (void)hipFree(h->pe_dev); h->pe_dev = nullptr; }
+        h->pe_cap = 0;
+    }
+    char* base = style ? h->sblob : h->wblob;
     for (uint32_t i = 0; i < count; ++i) {
         BlobEntry e;
         memcpy(&e, host_hdr + 16 + (size_t)i * sizeof(BlobEntry), sizeof e);
         e.name[63] = 0;
         if (e.offset + e.nbytes > nbytes) return fail(h, "weight blob: tensor %s out of range", e.name);
+        if ((strncmp(e.name, "sb.", 3) == 0) != style) return fail(h, "weight blob: tensor %s does not belong in the %s blob", e.name, style ? "SimBERT" : "generator");
         WeightEntry w;
         w.dtype = (int)e.dtype; w.ndim = (int)e.ndim; memcpy(w.dims, e.dims, sizeof w.dims);
-        w.ptr = h->wblob + e.offset; w.nbytes = e.nbytes;
+        w.ptr = base + e.offset; w.nbytes = e.nbytes;
         h->wt[e.name] = w;
     }
     return 0;
@@ -787,7 +798,8 @@ void ev_destroy(ev_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; ++i) if (h->arena[i]) (void)hipFree(h->arena[i]);
+    for (int i = 0; i < 3; ++i) if (h->arena[i]) (void)hipFree(h->arena[i]);
+    if (h->sblob) (void)hipFree(h->sblob);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->pe_dev) (void)hipFree(h->pe_dev);
     if (h->wblob && h->wblob_owned) (void)hipFree(h->wblob);
@@ -814,7 +826,7 @@ int ev_load_weights(ev_handle* h, const void* blob, size_t nbytes, const char*) 
     HIPCHK(h, hipMalloc((void**)&h->wblob, nbytes));
     h->wblob_owned = true; h->wbytes = nbytes;
     HIPCHK(h, hipMemcpy(h->wblob, blob, nbytes, hipMemcpyHostToDevice));
-    return parse_blob(h, (const char*)blob, nbytes);
+    return parse_blob(h, (const char*)blob, nbytes, false);
 }
 
 int ev_load_weights_device(ev_handle* h, const void* dptr, size_t nbytes, const char*) {
@@ -891,7 +903,7 @@ static void register_voc_taps(ev_handle* h, VocBufs& vb) {
 
 int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32_t* mel_lens, uint32_t flags, ev_result* out) {
     if (!h || !mel || !mel_lens || !out || B <= 0) return fail(h, "ev_vocoder: bad argument");
-    if (h->wt.empty()) return fail(h, "ev_vocoder: weights not loaded");
+    if (!h->wt.count("voc.post.w")) return fail(h, "ev_vocoder: weights not loaded");
     HIPCHK(h, hipSetDevice(h->device));
     const ev_config& c = h->cfg;
     const bool keep = c.keep_stages != 0;
@@ -952,7 +964,7 @@ int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32
 int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, const int64_t* speaker, const float* style,
                   const float* content, float alpha, uint32_t flags, ev_result* out) {
     if (!h || !ling || !cu || !speaker || !style || !content || !out || B <= 0) return fail(h, "ev_synthesize: bad argument");
-    if (h->wt.empty()) return fail(h, "ev_synthesize: weights not loaded");
+    if (!h->wt.count("tok_emb")) return fail(h, "ev_synthesize: weights not loaded");
     if (cu[0] != 0) return fail(h, "ev_synthesize: cu_seqlens[0] must be 0");
     HIPCHK(h, hipSetDevice(h->device));
     const ev_config& c = h->cfg;
@@ -1173,6 +1185,134 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     out->mel = fb.d_mel; out->durations = tb.d_dur; out->log_durations = tb.d_logd_packed; out->pitch = tb.d_pitch_packed;
     out->energy = tb.d_energy_packed; out->mel_lens = h->mel_lens.data(); out->mel_offsets = h->mel_offs.data();
     h->last_dur = tb.d_dur;
+    return 0;
+}
+
+// ------------------------------------------------------------------- SimBERT prompt / content encoder
+void ev_default_bert_config(ev_bert_config* c) {
+    memset(c, 0, sizeof *c);
+    c->vocab_size = 13685; c->hidden = 768; c->layers = 12; c->heads = 12; c->intermediate = 3072; c->max_position = 512;
+    c->type_vocab = 2; c->ln_eps = 1e-12f;
+}
+
+int ev_style_load_weights(ev_handle* h, const ev_bert_config* cfg, const void* blob, size_t nbytes) {
+    if (!h || !cfg || !blob) return fail(h, "ev_style_load_weights: null argument");
+    if (cfg->hidden % 128 || cfg->hidden > 1024 || cfg->heads <= 0 || cfg->hidden / cfg->heads != 64 || cfg->intermediate % 64 || cfg->layers <= 0)
+        return fail(h, "ev_style_load_weights: only hidden %% 128 == 0 (<= 1024) with 64-wide heads is built (BERT-base: 768 / 12)");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->sblob) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->sblob)); h->sblob = nullptr; }
+    h->style_loaded = false;
+    HIPCHK(h, hipMalloc((void**)&h->sblob, nbytes));
+    h->sbytes = nbytes;
+    HIPCHK(h, hipMemcpy(h->sblob, blob, nbytes, hipMemcpyHostToDevice));
+    if (parse_blob(h, (const char*)blob, nbytes, true)) return -1;
+    const WeightEntry* we = W(h, "sb.emb.word");
+    if (!we) return -1;
+    if ((int)we->dims[0] != cfg->vocab_size || (int)we->dims[1] != cfg->hidden) return fail(h, "ev_style_load_weights: word embedding %llu x %llu does not match the config", (unsigned long long)we->dims[0], (unsigned long long)we->dims[1]);
+    h->bcfg = *cfg;
+    h->style_loaded = true;
+    return 0;
+}
+
+// BertModel.forward -> pooler_output for B texts packed back to back (reference simbert.py:49-55 through
+// inference_am_vocoder_joint.py:25-38, which tokenises one text per call: attention_mask all ones; here each text attends to its
+// own tokens only, the same B = 1 semantics).  fp32-class arithmetic throughout (split-precision GEMMs, exact-fp32 MFMA
+// attention): the pooled output conditions the duration predictor, whose integer output must stay bit-exact.
+int ev_style_embed(ev_handle* h, int B, const int64_t* input_ids, const int64_t* token_type_ids, const int32_t* cu, uint32_t flags, float* out) {
+    if (!h || !input_ids || !cu || !out || B <= 0) return fail(h, "ev_style_embed: bad argument");
+    if (!h->style_loaded) return fail(h, "ev_style_embed: ev_style_load_weights first");
+    if (cu[0] != 0) return fail(h, "ev_style_embed: cu_seqlens[0] must be 0");
+    HIPCHK(h, hipSetDevice(h->device));
+    const ev_bert_config& bc = h->bcfg;
+    const int H = bc.hidden, I = bc.intermediate;
+    const bool dev_in = (flags & EV_FLAG_DEVICE_INPUTS) != 0;
+    const int NT = cu[B];
+    std::vector<int32_t> off(B), len(B);
+    int64_t rows = GAP; int max_len = 0;
+    for (int b = 0; b < B; ++b) {
+        const int n = cu[b + 1] - cu[b];
+        if (n <= 0) return fail(h, "ev_style_embed: text %d has %d tokens", b, n);
+        if (n > bc.max_position) return fail(h, "ev_style_embed: text %d has %d tokens > max_position_embeddings %d", b, n, bc.max_position);
+        off[b] = (int32_t)rows; len[b] = n; rows += n + GAP; max_len = std::max(max_len, n);
+    }
+    if (!dev_in)
+        for (int j = 0; j < NT; ++j)
+            if (input_ids[j] < 0 || input_ids[j] >= bc.vocab_size) return fail(h, "ev_style_embed: token id %lld at position %d outside [0, %d)", (long long)input_ids[j], j, bc.vocab_size);
+    const int Rt = (int)align_up((size_t)rows, ROW_ALIGN);
+    Buf x, t, qkv, ctx, ffn; int32_t *d_seq, *d_pos, *d_off, *d_len, *d_cu; uint8_t* d_valid; int64_t *d_ids, *d_tt; float* d_out;
+    size_t need = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        ArenaPlan ap{h, 2, pass == 0};
+        if (pass == 1 && arena_reserve(h, 2, need)) return -1;
+        d_seq = ap.arr<int32_t>(Rt); d_pos = ap.arr<int32_t>(Rt); d_valid = ap.arr<uint8_t>(Rt);
+        d_off = ap.arr<int32_t>(B); d_len = ap.arr<int32_t>(B); d_cu = ap.arr<int32_t>(B + 1);
+        d_ids = ap.arr<int64_t>(NT); d_tt = ap.arr<int64_t>(NT); d_out = ap.arr<float>((size_t)B * H);
+        x = ap.rows(Rt, H, 4); t = ap.rows(Rt, H, 4); qkv = ap.rows(Rt, 3 * H, 4); ctx = ap.rows(Rt, H, 4); ffn = ap.rows(Rt, I, 4);
+        need = ap.off;
+    }
+    if (pinned_reserve(h, (size_t)Rt * 9 + (size_t)B * 64 + 1024)) return -1;
+    {
+        int32_t* seq = (int32_t*)h->pinned; int32_t* pos = seq + Rt; int32_t* poff = pos + Rt; int32_t* plen = poff + B; uint8_t* valid = (uint8_t*)(plen + B);
+        for (int r = 0; r < Rt; ++r) { seq[r] = -1; pos[r] = 0; valid[r] = 0; }
+        for (int b = 0; b < B; ++b) {
+            poff[b] = off[b]; plen[b] = len[b];
+            for (int j = 0; j < len[b]; ++j) { const int r = off[b] + j; seq[r] = b; pos[r] = j; valid[r] = 1; }
+        }
+        HIPCHK(h, hipMemcpyAsync(d_seq, seq, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_pos, pos, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_off, poff, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_len, plen, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_valid, valid, (size_t)Rt, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_cu, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        const hipMemcpyKind kind = dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIPCHK(h, hipMemcpyAsync(d_ids, input_ids, (size_t)NT * 8, kind, h->stream));
+        if (token_type_ids) HIPCHK(h, hipMemcpyAsync(d_tt, token_type_ids, (size_t)NT * 8, kind, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    WPTR(wword, float, "sb.emb.word"); WPTR(wpos, float, "sb.emb.pos"); WPTR(wtype, float, "sb.emb.type");
+    WPTR(eg, float, "sb.emb.ln.g"); WPTR(eb, float, "sb.emb.ln.b");
+    launch_bert_embed(d_ids, token_type_ids ? d_tt : nullptr, d_cu, d_seq, d_pos, wword, wpos, wtype, bc.vocab_size, bc.max_position, bc.type_vocab,
+                      (float*)t.p, Rt, H, h->stream);
+    LayerNormParams ln{};
+    ln.ldx = H; ln.rows = Rt; ln.C = H; ln.eps = bc.ln_eps; ln.row_valid = d_valid; ln.ldo = H;
+    ln.x = (const float*)t.p; ln.gamma = eg; ln.beta = eb; ln.out32 = (float*)x.p;
+    launch_layernorm(ln, h->stream);
+    auto bert_gemm = [&](const std::string& base, ConvGemmParams& p) -> int {
+        const WeightEntry* hi = W(h, base + ".w16"); const WeightEntry* lo = W(h, base + ".w32l"); const WeightEntry* bias = W(h, base + ".b");
+        if (!hi || !lo || !bias) return -1;
+        p.dtype = DT_F32S; p.W = hi->ptr; p.W_lo = lo->ptr; p.bias = reinterpret_cast<const float*>(bias->ptr);
+        p.M = Rt; p.row_valid = d_valid;
+        return gemm(h, "style_gemm", p, (double)NT);
+    };
+    for (int i = 0; i < bc.layers; ++i) {
+        const std::string lp = "sb." + std::to_string(i);
+        WPTR(g1, float, lp + ".ln1.g"); WPTR(b1, float, lp + ".ln1.b"); WPTR(g2, float, lp + ".ln2.g"); WPTR(b2, float, lp + ".ln2.b");
+        ConvGemmParams p = gemm_defaults();
+        p.A = x.p; p.lda = H; p.N = 3 * H; p.K = H; p.out32 = (float*)qkv.p; p.ldo = 3 * H;
+        if (bert_gemm(lp + ".qkv", p)) return -1;
+        AttnParams ap{};
+        ap.qkv = qkv.p; ap.dtype = DT_F32; ap.ld = 3 * H; ap.C = H; ap.heads = bc.heads; ap.seq_off = d_off; ap.seq_len = d_len; ap.B = B;
+        ap.max_len = max_len; ap.out = ctx.p; ap.ldo = H;
+        launch_attention(ap, h->stream);
+        p = gemm_defaults();           // BertSelfOutput: LayerNorm(dense(ctx) + x)
+        p.A = ctx.p; p.lda = H; p.N = H; p.K = H; p.res = x.p; p.res_dtype = DT_F32; p.ldres = H; p.out32 = (float*)t.p; p.ldo = H;
+        if (bert_gemm(lp + ".out", p)) return -1;
+        ln.x = (const float*)t.p; ln.gamma = g1; ln.beta = b1; ln.out32 = (float*)x.p;
+        launch_layernorm(ln, h->stream);
+        p = gemm_defaults();           // BertIntermediate: gelu(dense(x)) (erf form)
+        p.A = x.p; p.lda = H; p.N = I; p.K = H; p.act = ACT_GELU; p.out32 = (float*)ffn.p; p.ldo = I;
+        if (bert_gemm(lp + ".ffn1", p)) return -1;
+        p = gemm_defaults();           // BertOutput: LayerNorm(dense(h) + x)
+        p.A = ffn.p; p.lda = I; p.N = H; p.K = I; p.res = x.p; p.res_dtype = DT_F32; p.ldres = H; p.out32 = (float*)t.p; p.ldo = H;
+        if (bert_gemm(lp + ".ffn2", p)) return -1;
+        ln.x = (const float*)t.p; ln.gamma = g2; ln.beta = b2; ln.out32 = (float*)x.p;
+        launch_layernorm(ln, h->stream);
+    }
+    WPTR(pw, float, "sb.pool.w"); WPTR(pb, float, "sb.pool.b");
+    launch_bert_pooler((const float*)x.p, H, d_off, pw, pb, d_out, B, H, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)B * H * 4, dev_in ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -86,6 +86,15 @@ struct AttnParams {
 };
 void launch_attention(const AttnParams& p, hipStream_t s);
 
+// SimBERT (BERT-base) embeddings: out[row] = word[ids] + type[type_ids] + pos[position] (transformers BertEmbeddings; the LayerNorm that
+// follows is launch_layernorm); pooler: out[b] = tanh(W x[first row of text b] + bias) (BertPooler).  reference
+// models/prompt_tts_modified/simbert.py:37,49-55.
+void launch_bert_embed(const int64_t* ids, const int64_t* type_ids /* or null = 0 */, const int32_t* cu_seqlens_dev, const int32_t* row_seq,
+                       const int32_t* row_pos, const float* word, const float* pos_emb, const float* type_emb, int vocab, int max_pos,
+                       int n_types, float* out, int rows, int C, hipStream_t s);
+void launch_bert_pooler(const float* x, int ldx, const int32_t* seq_off, const float* W, const float* bias, float* out, int B, int C,
+                        hipStream_t s);
+
 // u[b, :] = bias + Wspk . spk_emb[speaker[b]] + Wsty . style[b] + Wcon . content[b]
 // (columns 384..2303 of embed_projection1, reference model_open_source.py:110-111)
 void launch_cond_vector(const int64_t* speaker, const float* style, const float* content, const float* spk_emb, int n_speaker,

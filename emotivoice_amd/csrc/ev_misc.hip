@@ -31,18 +31,20 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 // ------------------------------------------------------------------ LayerNorm (+ optional dot head)
 // reference modules/encoder.py:112-127 (eps = 1e-12); variance.py:29-33 (channel LN in predictors);
-// variance.py:46,119 (Linear(C,1) head fused as dot_w/dot_b).  One wave per row, C <= 512, C % 128 == 0.
+// variance.py:46,119 (Linear(C,1) head fused as dot_w/dot_b).  One wave per row, C % 128 == 0; NV = float2 chunks per lane
+// (4: C <= 512, the acoustic model; 8: C <= 1024, the SimBERT encoder's 768).
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= p.rows) return;
     const int nv = p.C >> 7;   // float2 chunks per lane
     const bool valid = p.row_valid ? p.row_valid[row] != 0 : true;
-    float2 v[4];
+    float2 v[NV];
     float s = 0.f;
     const float* xr = p.x + (long)row * p.ldx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (i < nv) {
             v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2);
             s += v[i].x + v[i].y;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     const float mean = wave_sum(s) / (float)p.C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (i < nv) {
             const float a = v[i].x - mean, b = v[i].y - mean;
             q += a * a + b * b;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     const float rstd = 1.0f / sqrtf(var + p.eps);
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (i < nv) {
             const int c = i * 128 + lane * 2;
             const float2 g = *reinterpret_cast<const float2*>(p.gamma + c);
@@ -83,7 +85,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     }
 }
 void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    if (p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<4>), dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((layernorm_kernel<8>), dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------ SimBERT embeddings + pooler
+// reference models/prompt_tts_modified/simbert.py:37,49-55 -> transformers BertEmbeddings: word + position + token-type
+// embeddings, summed (the LayerNorm that follows is launch_layernorm with eps from the BERT config).
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* ids, const int64_t* type_ids, const int32_t* cu, const int32_t* row_seq,
+                                                         const int32_t* row_pos, const float* word, const float* pos_emb, const float* type_emb,
+                                                         int vocab, int max_pos, int n_types, float* out, int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = row_seq[row];
+    float* o = out + (long)row * C;
+    if (b < 0) {
+        for (int c = lane * 2; c < C; c += 128) *reinterpret_cast<float2*>(o + c) = make_float2(0.f, 0.f);
+        return;
+    }
+    const int pos = row_pos[row];
+    const long tok = min(max(ids[cu[b] + pos], 0L), (long)vocab - 1);
+    const long tt = type_ids ? min(max(type_ids[cu[b] + pos], 0L), (long)n_types - 1) : 0L;
+    const float* w = word + tok * C;
+    const float* pe = pos_emb + (long)min(pos, max_pos - 1) * C;
+    const float* te = type_emb + tt * C;
+    for (int c = lane * 2; c < C; c += 128) {
+        const float2 a = *reinterpret_cast<const float2*>(w + c), p2 = *reinterpret_cast<const float2*>(pe + c), t2 = *reinterpret_cast<const float2*>(te + c);
+        // summation order of BertEmbeddings.forward: (inputs_embeds + token_type_embeddings) + position_embeddings
+        *reinterpret_cast<float2*>(o + c) = make_float2((a.x + t2.x) + p2.x, (a.y + t2.y) + p2.y);
+    }
+}
+void launch_bert_embed(const int64_t* ids, const int64_t* type_ids, const int32_t* cu, const int32_t* row_seq, const int32_t* row_pos,
+                       const float* word, const float* pos_emb, const float* type_emb, int vocab, int max_pos, int n_types, float* out,
+                       int rows, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bert_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, type_ids, cu, row_seq, row_pos, word, pos_emb, type_emb,
+                       vocab, max_pos, n_types, out, rows, C);
+}
+
+// BertPooler: pooled[b] = tanh(W h[first token of text b] + bias); one wave per (output channel, text)
+__global__ __launch_bounds__(256) void bert_pooler_kernel(const float* x, int ldx, const int32_t* seq_off, const float* W, const float* bias,
+                                                          float* out, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const float* h = x + (long)seq_off[b] * ldx;
+    const float* w = W + (long)c * C;
+    float a = 0.f;
+    for (int i = lane; i < C; i += 64) a = fmaf(w[i], h[i], a);
+    a = wave_sum(a);
+    if (lane == 0) out[(long)b * C + c] = tanhf(a + bias[c]);
+}
+void launch_bert_pooler(const float* x, int ldx, const int32_t* seq_off, const float* W, const float* bias, float* out, int B, int C,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(bert_pooler_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, x, ldx, seq_off, W, bias, out, C);
 }
 
 // ------------------------------------------------------------------ embedding + positional encoding
@@ -411,7 +467,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
 // operands three contiguous float4 loads per lane.  Online softmax per query: 2 cross-lane shuffles per tile.
 template <int DK>
 __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParams p) {
-    static_assert(DK == 48, "d_k = 48: 12 reduction steps of 4, 3 output tiles of 16");
+    static_assert(DK % 16 == 0, "d_k = 48 (acoustic model): 12 reduction steps of 4, 3 output tiles of 16; d_k = 64 (SimBERT): 16 / 4");
+    constexpr int NJ = DK / 4, ND = DK / 16, NC = NJ / 4;      // reduction steps, output tiles, float4 loads per lane
     const int b = blockIdx.z, h = blockIdx.y;
     const int len = p.seq_len[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -422,28 +479,28 @@ __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParam
     const float* base = reinterpret_cast<const float*>(p.qkv);
     const float scale = 1.0f / sqrtf((float)DK);
 
-    float qv[12];
+    float qv[NJ];
     {
         const int qi = min(q0 + fr, len - 1);
-        const float4* qp = reinterpret_cast<const float4*>(base + (row0 + qi) * p.ld + h * DK + g * 12);
+        const float4* qp = reinterpret_cast<const float4*>(base + (row0 + qi) * p.ld + h * DK + g * NJ);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const float4 t = qp[c]; qv[4 * c] = t.x * scale; qv[4 * c + 1] = t.y * scale; qv[4 * c + 2] = t.z * scale; qv[4 * c + 3] = t.w * scale; }
+        for (int c = 0; c < NC; ++c) { const float4 t = qp[c]; qv[4 * c] = t.x * scale; qv[4 * c + 1] = t.y * scale; qv[4 * c + 2] = t.z * scale; qv[4 * c + 3] = t.w * scale; }
     }
-    f4 o[3];
+    f4 o[ND];
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < ND; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
 
-    float kv[12], vv[3][4];
+    float kv[NJ], vv[ND][4];
     const int ntile = (len + 15) >> 4;
 #define EV_ATT_LOAD(KT)                                                                                        \
     {                                                                                                          \
         const int kr_ = min((KT) * 16 + fr, len - 1);                                                          \
-        const float4* kp_ = reinterpret_cast<const float4*>(base + (row0 + kr_) * p.ld + p.C + h * DK + g * 12); \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c) { const float4 t = kp_[c]; kv[4 * c] = t.x; kv[4 * c + 1] = t.y; kv[4 * c + 2] = t.z; kv[4 * c + 3] = t.w; } \
+        const float4* kp_ = reinterpret_cast<const float4*>(base + (row0 + kr_) * p.ld + p.C + h * DK + g * NJ); \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c) { const float4 t = kp_[c]; kv[4 * c] = t.x; kv[4 * c + 1] = t.y; kv[4 * c + 2] = t.z; kv[4 * c + 3] = t.w; } \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
             const float* vp_ = base + (row0 + min((KT) * 16 + 4 * g + i, len - 1)) * p.ld + 2 * p.C + h * DK + fr; \
-            _Pragma("unroll") for (int dt = 0; dt < 3; ++dt) vv[dt][i] = vp_[dt * 16];                          \
+            _Pragma("unroll") for (int dt = 0; dt < ND; ++dt) vv[dt][i] = vp_[dt * 16];                          \
         }                                                                                                      \
     }
     EV_ATT_LOAD(0)
@@ -451,10 +508,10 @@ __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParam
         // S^T tile
         f4 st = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 12; ++j) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j], qv[j], st, 0, 0, 0);
-        float vcur[3][4];
+        for (int j = 0; j < NJ; ++j) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j], qv[j], st, 0, 0, 0);
+        float vcur[ND][4];
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
+        for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) vcur[dt][i] = vv[dt][i];
         if (kt + 1 < ntile) EV_ATT_LOAD(kt + 1)          // next tile's K / V rows arrive under this tile's softmax and PV
@@ -477,7 +534,7 @@ __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParam
         for (int i = 0; i < 4; ++i) { pr[i] = expf(sc[i] - mn); ps += pr[i]; }
         l = l * alpha + ps;                          // per-lane partial row sum; the 4 lane groups are added at the end
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt) {
+        for (int dt = 0; dt < ND; ++dt) {
             o[dt] *= alpha;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vcur[dt][i], pr[i], o[dt], 0, 0, 0);
@@ -490,7 +547,7 @@ __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParam
         const float inv = 1.0f / l;
         float* op = reinterpret_cast<float*>(p.out) + (row0 + q0 + fr) * p.ldo + h * DK + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
+        for (int dt = 0; dt < ND; ++dt)
             *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
     }
 }
@@ -507,6 +564,10 @@ void launch_attention(const AttnParams& p, hipStream_t s) {
         static const bool valu32 = getenv("EV_ATTN_VALU") != nullptr;   // A/B switch: the one-query-per-lane VALU kernel
         if (!valu32 && p.C / p.heads == 48) {
             hipLaunchKernelGGL((attention_mfma_f32_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+            return;
+        }
+        if (p.C / p.heads == 64) {       // SimBERT encoder (12 heads x 64)
+            hipLaunchKernelGGL((attention_mfma_f32_kernel<64>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
             return;
         }
         hipLaunchKernelGGL((attention_kernel<float, 48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(64), 0, s, p);

@@ -108,6 +108,33 @@ class EVEngine:
         self._blob_keepalive = keepalive
         self._check(self._lib.ev_load_weights_device(self._h, C.c_void_p(dptr), nbytes, None))
 
+    # -- SimBERT prompt / content encoder (ev_style_*)
+    def style_load(self, blob: bytes, cfg: dict):
+        """blob / cfg from packer.pack_bert_state_dict."""
+        bc = _ffi.ev_bert_config()
+        self._lib.ev_default_bert_config(C.byref(bc))
+        for k in ("vocab_size", "hidden", "layers", "intermediate", "max_position", "type_vocab"):
+            setattr(bc, k, int(cfg[k]))
+        bc.heads = int(cfg.get("heads", bc.hidden // 64))
+        bc.ln_eps = float(cfg.get("ln_eps", 1e-12))
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._check(self._lib.ev_style_load_weights(self._h, C.byref(bc), C.cast(buf, C.c_void_p), len(blob)))
+        self.style_hidden = int(bc.hidden)
+
+    def style_embed(self, id_lists: Sequence[np.ndarray], type_lists: Optional[Sequence[np.ndarray]] = None) -> np.ndarray:
+        """pooled_output (B, hidden) of B token-id sequences (one text each: [CLS] ... [SEP])."""
+        B = len(id_lists)
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int64).reshape(-1) for x in id_lists]))
+        cu = np.zeros(B + 1, np.int32)
+        cu[1:] = np.cumsum([len(x) for x in id_lists])
+        tt = None
+        if type_lists is not None:
+            tt = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int64).reshape(-1) for x in type_lists]))
+        out = np.empty((B, self.style_hidden), np.float32)
+        self._check(self._lib.ev_style_embed(self._h, B, ids.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p) if tt is not None else None,
+                                             cu.ctypes.data_as(C.c_void_p), 0, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # -- raw calls (host or device pointers)
     def synthesize_raw(self, B: int, ling_ptr: int, cu_seqlens: np.ndarray, speaker_ptr: int, style_ptr: int,
                        content_ptr: int, alpha: float = 1.0, flags: int = 0) -> _ffi.ev_result:

@@ -38,9 +38,12 @@ from .text_io import HashStyleEmbedder, phonemes_to_ids, read_table, read_text_f
 def _load_config(config_folder: str):
     """reference :151-155: sys.path.append(<cwd>/<config_folder>); from config import Config; Config()."""
     path = config_folder if os.path.isabs(config_folder) else os.path.join(os.path.dirname(os.path.abspath("__file__")), config_folder)
-    sys.path.append(path)
     sys.modules.pop("config", None)
-    from config import Config           # the caller's config folder, like the reference
+    sys.path.insert(0, path)            # (the reference appends; first place here so that a second call with another folder wins)
+    try:
+        from config import Config       # the caller's config folder, like the reference
+    finally:
+        sys.path.remove(path)
     return Config()
 
 

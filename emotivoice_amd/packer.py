@@ -261,3 +261,60 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
     b.add("voc.post.b", f32(f"{g}.conv_post.bias").reshape(1), DT_F32)
     blob, manifest = b.finish()
     return blob, json.dumps(manifest)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SimBERT prompt / content encoder (reference models/prompt_tts_modified/simbert.py:33-46: StyleEncoder.bert =
+# AutoModel.from_pretrained(config.bert_path), a transformers BertModel; the four classification heads and
+# style_embed_proj are training-only and do not reach "pooled_output").
+def pack_bert_state_dict(sd: Dict[str, object]) -> Tuple[bytes, str, dict]:
+    """Pack a StyleEncoder / BertModel state dict for ev_style_load_weights.  Accepts the keys of the reference's StyleEncoder
+    (``bert.embeddings...``, optionally behind the DDP ``module.`` prefix its checkpoints carry, predict.py:113-117), or of a bare
+    transformers BertModel (``embeddings...``).  Returns (blob, manifest_json, config dict for ev_bert_config).
+    GEMM weights are stored as the fp16 hi / lo pair of the split-precision kernel; every name carries the "sb." prefix."""
+    if any(k.startswith("module.") for k in sd):
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    if any(k.startswith("bert.") for k in sd):
+        sd = {k[5:]: v for k, v in sd.items() if k.startswith("bert.")}
+    f32 = lambda k: _np(sd[k]).astype(np.float32)  # noqa: E731
+    b = _Blob()
+    word = f32("embeddings.word_embeddings.weight")
+    pos = f32("embeddings.position_embeddings.weight")
+    typ = f32("embeddings.token_type_embeddings.weight")
+    H = word.shape[1]
+    b.add("sb.emb.word", word, DT_F32)
+    b.add("sb.emb.pos", pos, DT_F32)
+    b.add("sb.emb.type", typ, DT_F32)
+    b.add("sb.emb.ln.g", f32("embeddings.LayerNorm.weight"), DT_F32)
+    b.add("sb.emb.ln.b", f32("embeddings.LayerNorm.bias"), DT_F32)
+    n_layers = 0
+    while f"encoder.layer.{n_layers}.attention.self.query.weight" in sd:
+        n_layers += 1
+    inter = 0
+
+    def gemm(name, w, bias):
+        w = np.ascontiguousarray(w, np.float32)[:, None, :]       # [N][taps = 1][K]
+        b.add(name + ".w16", w, DT_F16)
+        b.lo(name + ".w32l", w)
+        b.add(name + ".b", bias, DT_F32)
+
+    for i in range(n_layers):
+        p = f"encoder.layer.{i}"
+        wq = [f32(f"{p}.attention.self.{n}.weight") for n in ("query", "key", "value")]
+        bq = [f32(f"{p}.attention.self.{n}.bias") for n in ("query", "key", "value")]
+        gemm(f"sb.{i}.qkv", np.concatenate(wq, 0), np.concatenate(bq, 0))
+        gemm(f"sb.{i}.out", f32(f"{p}.attention.output.dense.weight"), f32(f"{p}.attention.output.dense.bias"))
+        b.add(f"sb.{i}.ln1.g", f32(f"{p}.attention.output.LayerNorm.weight"), DT_F32)
+        b.add(f"sb.{i}.ln1.b", f32(f"{p}.attention.output.LayerNorm.bias"), DT_F32)
+        w1 = f32(f"{p}.intermediate.dense.weight")
+        inter = w1.shape[0]
+        gemm(f"sb.{i}.ffn1", w1, f32(f"{p}.intermediate.dense.bias"))
+        gemm(f"sb.{i}.ffn2", f32(f"{p}.output.dense.weight"), f32(f"{p}.output.dense.bias"))
+        b.add(f"sb.{i}.ln2.g", f32(f"{p}.output.LayerNorm.weight"), DT_F32)
+        b.add(f"sb.{i}.ln2.b", f32(f"{p}.output.LayerNorm.bias"), DT_F32)
+    b.add("sb.pool.w", f32("pooler.dense.weight"), DT_F32)
+    b.add("sb.pool.b", f32("pooler.dense.bias"), DT_F32)
+    blob, manifest = b.finish()
+    cfg = dict(vocab_size=int(word.shape[0]), hidden=int(H), layers=n_layers, intermediate=int(inter), max_position=int(pos.shape[0]),
+               type_vocab=int(typ.shape[0]))
+    return blob, json.dumps(manifest), cfg

@@ -190,3 +190,52 @@ def synth_inputs(seed: int, lengths: List[int], speakers: List[int] | None = Non
         spk = 0 if speakers is None else int(speakers[i])
         out.append(dict(ling=ling, speaker=spk, style=style, content=content))
     return out
+
+
+def synth_bert_state_dict(seed: int = 0, vocab_size: int = 13685, hidden: int = 768, layers: int = 12, intermediate: int = 3072,
+                          max_position: int = 512, type_vocab: int = 2, prefix: str = "bert.") -> Dict[str, np.ndarray]:
+    """Seeded synthetic weights with the keys / shapes of the reference's StyleEncoder.bert (a transformers BertModel of
+    WangZeJun/simbert-base-chinese geometry, which is a download that is not in the container: predict.py:47-53).  Linear weights
+    N(0, 0.05) (wider than HF's 0.02 init so that attention and the tanh pooler are exercised away from their linear regime),
+    perturbed LayerNorm parameters, non-zero biases."""
+    rng = np.random.default_rng(seed + 1000)
+    sd: Dict[str, np.ndarray] = {}
+    n = lambda *shape, s=0.05: (rng.standard_normal(shape) * s).astype(np.float32)  # noqa: E731
+
+    def ln(key):
+        sd[prefix + key + ".weight"] = (1.0 + 0.1 * rng.standard_normal(hidden)).astype(np.float32)
+        sd[prefix + key + ".bias"] = (0.05 * rng.standard_normal(hidden)).astype(np.float32)
+
+    sd[prefix + "embeddings.word_embeddings.weight"] = n(vocab_size, hidden, s=0.5)
+    sd[prefix + "embeddings.position_embeddings.weight"] = n(max_position, hidden, s=0.2)
+    sd[prefix + "embeddings.token_type_embeddings.weight"] = n(type_vocab, hidden, s=0.2)
+    ln("embeddings.LayerNorm")
+    for i in range(layers):
+        p = f"{prefix}encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            sd[p + f"attention.self.{nm}.weight"] = n(hidden, hidden)
+            sd[p + f"attention.self.{nm}.bias"] = n(hidden, s=0.02)
+        sd[p + "attention.output.dense.weight"] = n(hidden, hidden)
+        sd[p + "attention.output.dense.bias"] = n(hidden, s=0.02)
+        ln(f"encoder.layer.{i}.attention.output.LayerNorm")
+        sd[p + "intermediate.dense.weight"] = n(intermediate, hidden)
+        sd[p + "intermediate.dense.bias"] = n(intermediate, s=0.02)
+        sd[p + "output.dense.weight"] = n(hidden, intermediate, s=0.03)
+        sd[p + "output.dense.bias"] = n(hidden, s=0.02)
+        ln(f"encoder.layer.{i}.output.LayerNorm")
+    sd[prefix + "pooler.dense.weight"] = n(hidden, hidden, s=0.03)
+    sd[prefix + "pooler.dense.bias"] = n(hidden, s=0.02)
+    return sd
+
+
+def synth_token_ids(seed: int, lengths: List[int], vocab_size: int = 13685) -> List[np.ndarray]:
+    """Token id sequences shaped like a BERT tokenizer's output: [CLS] = 101 ... [SEP] = 102."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for n in lengths:
+        ids = rng.integers(103, vocab_size, size=n, dtype=np.int64)
+        ids[0] = 101
+        if n > 1:
+            ids[-1] = 102
+        out.append(ids)
+    return out

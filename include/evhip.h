@@ -152,6 +152,32 @@ int ev_set_forced_durations(ev_handle* h, const int64_t* durations, int64_t n);
 int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32_t* mel_lens,
                uint32_t flags, ev_result* out);
 
+/* SimBERT prompt / content encoder on the device (reference models/prompt_tts_modified/simbert.py:48-72, called twice per utterance
+ * at inference_am_vocoder_joint.py:25-38,106-107 and predict.py:142-158 -- on the CPU there): BERT-base forward, the result is
+ * outputs["pooled_output"] = tanh(W_pool h[CLS] + b_pool), which the callers pass as inputs_style_embedding /
+ * inputs_content_embedding.  The weights are a second packed blob (emotivoice_amd/packer.py: pack_bert_state_dict, from the
+ * StyleEncoder state dict); fp32-class arithmetic (split-precision GEMMs, exact-fp32 MFMA attention). */
+typedef struct ev_bert_config {
+    int32_t vocab_size;        /* 13685 (WangZeJun/simbert-base-chinese) */
+    int32_t hidden;            /* 768  */
+    int32_t layers;            /* 12   */
+    int32_t heads;             /* 12 (64-wide heads) */
+    int32_t intermediate;      /* 3072 */
+    int32_t max_position;      /* 512  */
+    int32_t type_vocab;        /* 2    */
+    float   ln_eps;            /* 1e-12 */
+    int32_t reserved[8];
+} ev_bert_config;
+void ev_default_bert_config(ev_bert_config* cfg);
+int ev_style_load_weights(ev_handle* h, const ev_bert_config* cfg, const void* blob, size_t nbytes);   /* host pointer, copied */
+/* B texts, token ids packed back to back (what the tokenizer returns per text: [CLS] ... [SEP]).
+ *   input_ids      (cu_seqlens[B],) int64          = tokenizer(...)["input_ids"]
+ *   token_type_ids (cu_seqlens[B],) int64 or NULL  = tokenizer(...)["token_type_ids"] (NULL: all 0)
+ *   cu_seqlens     (B+1,) int32 HOST pointer       (attention_mask is all ones per text: each text attends to its own tokens)
+ *   out            (B, hidden) fp32: host pointer, or a device pointer with EV_FLAG_DEVICE_INPUTS (then ids are device pointers too) */
+int ev_style_embed(ev_handle* h, int B, const int64_t* input_ids, const int64_t* token_type_ids, const int32_t* cu_seqlens,
+                   uint32_t flags, float* out);
+
 /* Copy a named stage tap (SURVEY.md Appendix C names) of the LAST call to host memory as fp32
  * (integer taps as int64), in the packed utterance-major layout (rows x channels, valid rows only).
  * Returns the number of bytes written, or a negative error (e.g. cap too small, unknown name,
