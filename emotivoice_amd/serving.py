@@ -1,0 +1,189 @@
+"""Serving shell on top of the FFI: dynamic batching + an OpenAI-compatible ``/v1/audio/speech`` endpoint.
+
+Reference: openaiapi.py:111-184 -- one synchronous generator call per HTTP request (B = 1), speed changed afterwards by
+pyrubberband time-stretching (:170-171).  Here:
+  * requests from concurrent clients are collected by ``DynamicBatcher`` for at most ``max_wait_ms`` (or until ``max_batch`` /
+    ``max_tokens``) and synthesised in ONE ev_synthesize call -- the engine evaluates every utterance with B = 1 semantics, so
+    batching changes latency and throughput, never the audio (tests/test_gpu_parity.py::test_batch_invariance_bit_exact);
+  * ``speed`` maps to the model's own duration scale alpha = 1 / speed (GaussianUpsampling's alpha, modules/alignment.py:183)
+    instead of a time-stretch of the finished waveform; requests with different speeds form separate batches;
+  * the text front-end (G2P) and the tokenizer are host-side callables supplied by the caller (the reference's frontend.py /
+    AutoTokenizer), the style encoder is the device SimBERT (emotivoice_amd/simbert.py) or any ``text -> 768-vector`` callable.
+Response formats: ``wav`` (16-bit PCM in a RIFF container) and ``pcm`` (raw little-endian int16); mp3 needs pydub / ffmpeg,
+which are not part of this package.
+"""
+from __future__ import annotations
+
+import io
+import queue
+import threading
+import time
+import wave
+from concurrent.futures import Future
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .text_io import wav_float_to_int16
+
+
+@dataclass
+class SynthesisRequest:
+    ling: np.ndarray                 # (N,) int64 phoneme ids
+    speaker: int
+    style: np.ndarray                # (768,)
+    content: np.ndarray              # (768,)
+    alpha: float = 1.0               # duration scale (1 / speed)
+    future: Future = field(default_factory=Future)
+    t_submit: float = field(default_factory=time.perf_counter)
+
+
+class DynamicBatcher:
+    """Collects requests into batches for ``synth_fn(utts, alpha) -> list of float waveforms`` (one per utterance, in order).
+    One worker thread owns the engine handle (the handle is not thread-safe, include/evhip.h)."""
+
+    def __init__(self, synth_fn: Callable[[List[dict], float], Sequence[np.ndarray]], max_batch: int = 32, max_wait_ms: float = 5.0,
+                 max_tokens: int = 16384):
+        self.synth_fn, self.max_batch, self.max_wait, self.max_tokens = synth_fn, max_batch, max_wait_ms * 1e-3, max_tokens
+        self._q: "queue.Queue[Optional[SynthesisRequest]]" = queue.Queue()
+        self._carry: List[SynthesisRequest] = []
+        self.batches: List[int] = []          # sizes of the batches formed so far (observability / tests)
+        self._stop = False
+        self._thread = threading.Thread(target=self._loop, name="ev-batcher", daemon=True)
+        self._thread.start()
+
+    def submit(self, ling, speaker: int, style, content, alpha: float = 1.0) -> Future:
+        if self._stop:
+            raise RuntimeError("batcher is closed")
+        req = SynthesisRequest(np.asarray(ling, np.int64), int(speaker), np.asarray(style, np.float32), np.asarray(content, np.float32), float(alpha))
+        self._q.put(req)
+        return req.future
+
+    def close(self):
+        self._stop = True
+        self._q.put(None)
+        self._thread.join(timeout=30)
+
+    def _take_batch(self) -> List[SynthesisRequest]:
+        """Block for the first request, then keep collecting until the batch is full, the token budget is reached or
+        ``max_wait`` has passed since the first request arrived.  Requests with another alpha are carried to the next batch."""
+        first = self._carry.pop(0) if self._carry else self._q.get()
+        if first is None:
+            return []
+        batch, tokens = [first], len(first.ling)
+        deadline = time.perf_counter() + self.max_wait
+        keep = []
+        for r in self._carry:                           # carried requests first (they have waited longest)
+            if r.alpha == first.alpha and len(batch) < self.max_batch and tokens + len(r.ling) <= self.max_tokens:
+                batch.append(r); tokens += len(r.ling)
+            else:
+                keep.append(r)
+        self._carry = keep
+        while len(batch) < self.max_batch and tokens < self.max_tokens:
+            timeout = deadline - time.perf_counter()
+            if timeout <= 0:
+                break
+            try:
+                r = self._q.get(timeout=timeout)
+            except queue.Empty:
+                break
+            if r is None:
+                self._q.put(None)
+                break
+            if r.alpha == first.alpha and tokens + len(r.ling) <= self.max_tokens:
+                batch.append(r); tokens += len(r.ling)
+            else:
+                self._carry.append(r)
+        return batch
+
+    def _loop(self):
+        while True:
+            batch = self._take_batch()
+            if not batch:
+                if self._stop and not self._carry:
+                    return
+                continue
+            self.batches.append(len(batch))
+            try:
+                wavs = self.synth_fn([dict(ling=r.ling, speaker=r.speaker, style=r.style, content=r.content) for r in batch], batch[0].alpha)
+                if len(wavs) != len(batch):
+                    raise RuntimeError("synth_fn returned %d waveforms for %d requests" % (len(wavs), len(batch)))
+                for r, w in zip(batch, wavs):
+                    r.future.set_result(np.array(w, np.float32, copy=True))
+            except Exception as e:          # the whole batch fails together; other batches are unaffected
+                for r in batch:
+                    if not r.future.done():
+                        r.future.set_exception(e)
+
+
+def engine_synth_fn(engine) -> Callable[[List[dict], float], Sequence[np.ndarray]]:
+    """``synth_fn`` of a DynamicBatcher for an EVEngine."""
+    return lambda utts, alpha: engine.synthesize(utts, alpha=alpha)["wav_list"]
+
+
+def encode_audio(wav_f32: np.ndarray, response_format: str, sample_rate: int) -> bytes:
+    pcm = wav_float_to_int16(wav_f32)              # the reference's int16 epilogue (openaiapi.py:147-148)
+    if response_format == "pcm":
+        return pcm.tobytes()
+    if response_format == "wav":
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sample_rate)
+            w.writeframes(pcm.tobytes())
+        return buf.getvalue()
+    raise ValueError("response_format %r is not available (wav, pcm); mp3 needs pydub / ffmpeg" % response_format)
+
+
+class TTSService:
+    """text -> audio: G2P, token / speaker lookup, style + content embedding, batched synthesis.  All host-side pieces are
+    injected: ``g2p(text) -> phoneme string`` (the reference's frontend.g2p_cn_en), ``embed(text) -> (768,)`` (the device SimBERT
+    through a tokenizer, or a placeholder)."""
+
+    def __init__(self, batcher: DynamicBatcher, token2id: Dict[str, int], speaker2id: Dict[str, int], g2p: Callable[[str], str],
+                 embed: Callable[[str], np.ndarray], sample_rate: int = 16000):
+        self.batcher, self.token2id, self.speaker2id, self.g2p, self.embed, self.sample_rate = batcher, token2id, speaker2id, g2p, embed, sample_rate
+
+    def submit(self, text: str, voice: str, prompt: str = "", speed: float = 1.0) -> Future:
+        if not (0.25 <= speed <= 4.0):
+            raise ValueError("speed must be within [0.25, 4]")
+        ling = np.array([self.token2id[ph] for ph in self.g2p(text).split()], np.int64)       # KeyError like openaiapi.py:128
+        return self.batcher.submit(ling, self.speaker2id[voice], self.embed(prompt), self.embed(text), alpha=1.0 / speed)
+
+    def speech(self, text: str, voice: str, prompt: str = "", speed: float = 1.0, response_format: str = "wav", timeout: float = 120.0) -> bytes:
+        return encode_audio(self.submit(text, voice, prompt, speed).result(timeout=timeout), response_format, self.sample_rate)
+
+
+try:          # the request schema lives at module level: FastAPI resolves the handler's annotations in the module namespace
+    from pydantic import BaseModel as _BaseModel
+
+    class SpeechRequest(_BaseModel):
+        """openaiapi.py:150-157 (default response_format here is wav: mp3 needs pydub / ffmpeg)."""
+        input: str
+        voice: str = "8051"
+        prompt: Optional[str] = ""
+        language: Optional[str] = "zh_us"
+        model: Optional[str] = "emoti-voice"
+        response_format: Optional[str] = "wav"
+        speed: Optional[float] = 1.0
+except ImportError:          # pydantic / fastapi are only needed by create_app
+    SpeechRequest = None
+
+
+def create_app(service: TTSService):
+    """FastAPI application with the reference's route and request schema (openaiapi.py:150-184)."""
+    from fastapi import FastAPI, HTTPException, Response
+
+    app = FastAPI()
+
+    @app.post("/v1/audio/speech")
+    def text_to_speech(req: SpeechRequest):
+        try:
+            data = service.speech(req.input, req.voice, req.prompt or "", req.speed or 1.0, req.response_format or "wav")
+        except KeyError as e:
+            raise HTTPException(status_code=400, detail="unknown voice or phoneme: %s" % e)
+        except ValueError as e:
+            raise HTTPException(status_code=400, detail=str(e))
+        return Response(content=data, media_type="audio/%s" % (req.response_format or "wav"))
+
+    return app

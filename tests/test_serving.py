@@ -1,0 +1,115 @@
+"""Host logic of the serving shell and the front-end pool (no GPU: the engine is replaced by a fake synth_fn)."""
+import io
+import threading
+import time
+import wave
+
+import numpy as np
+import pytest
+
+from emotivoice_amd.frontend_pool import FrontendPool
+from emotivoice_amd.serving import DynamicBatcher, TTSService, create_app, encode_audio
+
+
+def _fake_synth(log, delay=0.02):
+    def fn(utts, alpha):
+        log.append((len(utts), alpha))
+        time.sleep(delay)                                  # the "GPU" is busy: later requests pile up meanwhile
+        return [np.full(int(256 * len(u["ling"]) * alpha), float(u["speaker"]) / 100.0, np.float32) for u in utts]
+    return fn
+
+
+def test_dynamic_batcher_batches_routes_and_groups_by_alpha():
+    log = []
+    b = DynamicBatcher(_fake_synth(log), max_batch=8, max_wait_ms=30)
+    futs = {}
+
+    def client(i):
+        futs[i] = b.submit(np.arange(3 + i % 5), speaker=i, style=np.zeros(768), content=np.zeros(768), alpha=2.0 if i % 7 == 0 else 1.0)
+
+    ths = [threading.Thread(target=client, args=(i,)) for i in range(40)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for i in range(40):
+        w = futs[i].result(timeout=10)
+        alpha = 2.0 if i % 7 == 0 else 1.0
+        assert w.shape == (int(256 * (3 + i % 5) * alpha),) and np.allclose(w, i / 100.0)      # each client gets ITS audio
+    b.close()
+    assert sum(n for n, _ in log) == 40 and max(n for n, _ in log) <= 8
+    assert len(log) < 40                                   # requests were actually batched
+    assert all(a in (1.0, 2.0) for _, a in log) and {a for _, a in log} == {1.0, 2.0}
+    assert b.batches == [n for n, _ in log]
+
+
+def test_batcher_failure_is_confined_to_its_batch():
+    calls = []
+
+    def fn(utts, alpha):
+        calls.append(len(utts))
+        if any(u["speaker"] == 13 for u in utts):
+            raise RuntimeError("boom")
+        return [np.zeros(4, np.float32) for _ in utts]
+
+    b = DynamicBatcher(fn, max_batch=4, max_wait_ms=1)
+    bad = b.submit(np.arange(3), 13, np.zeros(768), np.zeros(768))
+    with pytest.raises(RuntimeError):
+        bad.result(timeout=5)
+    ok = b.submit(np.arange(3), 1, np.zeros(768), np.zeros(768))
+    assert ok.result(timeout=5).shape == (4,)
+    b.close()
+    with pytest.raises(RuntimeError):
+        b.submit(np.arange(3), 1, np.zeros(768), np.zeros(768))
+
+
+def test_token_budget_splits_batches():
+    log = []
+    b = DynamicBatcher(_fake_synth(log, 0.0), max_batch=64, max_wait_ms=50, max_tokens=100)
+    futs = [b.submit(np.arange(40), 0, np.zeros(768), np.zeros(768)) for _ in range(5)]
+    [f.result(timeout=5) for f in futs]
+    b.close()
+    assert all(n <= 2 for n, _ in log) and sum(n for n, _ in log) == 5
+
+
+def test_encode_audio_formats():
+    x = np.array([0.0, 0.5, -0.5, 0.99997], np.float32)
+    assert np.frombuffer(encode_audio(x, "pcm", 16000), np.int16).tolist() == [0, 16384, -16384, 32767]
+    with wave.open(io.BytesIO(encode_audio(x, "wav", 16000))) as w:
+        assert (w.getframerate(), w.getsampwidth(), w.getnchannels(), w.getnframes()) == (16000, 2, 1, 4)
+    with pytest.raises(ValueError):
+        encode_audio(x, "mp3", 16000)
+
+
+def test_openai_compatible_endpoint():
+    pytest.importorskip("fastapi")
+    pytest.importorskip("httpx")
+    from fastapi.testclient import TestClient
+    log = []
+    b = DynamicBatcher(_fake_synth(log, 0.0), max_batch=4, max_wait_ms=1)
+    tok = {"<sos/eos>": 0, "a": 1, "b": 2}
+    svc = TTSService(b, tok, {"8051": 0, "9000": 7}, g2p=lambda t: "<sos/eos> " + " ".join("a" if c < "n" else "b" for c in t if c.isalpha()) + " <sos/eos>",
+                     embed=lambda t: np.zeros(768, np.float32))
+    client = TestClient(create_app(svc))
+    r = client.post("/v1/audio/speech", json={"input": "hello", "voice": "9000", "response_format": "wav", "speed": 2.0})
+    assert r.status_code == 200 and r.headers["content-type"] == "audio/wav"
+    with wave.open(io.BytesIO(r.content)) as w:
+        assert w.getframerate() == 16000 and w.getnframes() == int(256 * 7 * 0.5)      # 7 phonemes, speed 2 -> alpha 0.5
+    assert log[-1] == (1, 0.5)
+    assert client.post("/v1/audio/speech", json={"input": "hello", "voice": "nobody"}).status_code == 400
+    assert client.post("/v1/audio/speech", json={"input": "hello", "voice": "8051", "response_format": "mp3"}).status_code == 400
+    assert client.post("/v1/audio/speech", json={"input": "hello", "voice": "8051", "speed": 9.0}).status_code == 400
+    b.close()
+
+
+def _toy_g2p(text):
+    return "<sos/eos> " + " ".join("p%d" % (ord(c) % 50) for c in text if not c.isspace()) + " <sos/eos>"
+
+
+def test_frontend_pool_keeps_order_and_matches_serial():
+    texts = ["line %d with some words %s" % (i, "x" * (i % 13)) for i in range(500)]
+    serial = [_toy_g2p(t) for t in texts]
+    with FrontendPool(_toy_g2p, workers=4, chunk=16) as pool:
+        assert pool.map(texts) == serial
+        assert list(pool.stream(iter(texts))) == serial
+        assert pool.throughput(texts) > 0
+    with FrontendPool(_toy_g2p, workers=1) as pool:
+        assert pool.map(texts[:20]) == serial[:20]
