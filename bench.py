@@ -153,6 +153,14 @@ def roofline_block(eng, work, torch, strict):
     torch.cuda.synchronize()
     stats = {s["name"]: s for s in eng.kernel_stats()}
     stages = eng.timings()
+    dump = os.environ.get("EV_DUMP_LAUNCHES")             # per-launch table (kernel, shape, ms, TF/s, GB/s) for profiles/
+    if dump:
+        recs = eng.launch_records()
+        for r in recs:
+            r["TFLOPs"] = round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["ms"] > 0 and r["flops"] > 0 else None
+            r["GBps"] = round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 and r["bytes"] > 0 else None
+        with open(dump + (".strict" if strict else ""), "w") as f:
+            json.dump(recs, f, indent=0)
     eng.set_profiling(False)
     f1 = int(res.total_frames)
     B = int(res.batch)

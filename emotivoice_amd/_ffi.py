@@ -50,6 +50,11 @@ class ev_kernel_stat(C.Structure):
                 ("bytes", C.c_double)]
 
 
+class ev_launch_record(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("taps", C.c_int32), ("dil", C.c_int32),
+                ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 class ev_conv_gemm_desc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("W_lo", C.c_void_p), ("bias", C.c_void_p),
@@ -88,6 +93,8 @@ SIGNATURES = {
     "ev_kernel_stat_count": (C.c_int, [_P]),
     "ev_get_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(ev_kernel_stat)]),
     "ev_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "ev_launch_record_count": (C.c_int, [_P]),
+    "ev_get_launch_record": (C.c_int, [_P, C.c_int, C.POINTER(ev_launch_record)]),
     "ev_default_bert_config": (None, [C.POINTER(ev_bert_config)]),
     "ev_style_load_weights": (C.c_int, [_P, C.POINTER(ev_bert_config), _P, C.c_size_t]),
     "ev_style_embed": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_uint32, _P]),

@@ -48,7 +48,8 @@ struct Buf {              // activation buffer with PAD_ROWS of slack on both si
 struct Tap { const void* ptr; int dtype; int ld; int C; int level; /* 0 token, 1 frame, 2+s vocoder stage s */ int shift; };
 
 struct KStat { std::string name; int launches = 0; float ms = 0; double flops = 0, bytes = 0; };
-struct PendingEvt { hipEvent_t a, b; int stat; };
+struct PendingEvt { hipEvent_t a, b; int stat; int rec; };
+struct LaunchRec { std::string name; int M = 0, N = 0, K = 0, taps = 0, dil = 0; float ms = 0; double flops = 0, bytes = 0; };
 
 }  // namespace
 
@@ -86,6 +87,7 @@ struct ev_handle {
     // profiling
     bool profiling = false;
     std::vector<KStat> stats; std::map<std::string, int> stat_idx;
+    std::vector<LaunchRec> launches;          // one record per launch of the last profiled call, in launch order
     std::vector<PendingEvt> pending; std::vector<hipEvent_t> evt_pool; size_t evt_next = 0;
     std::map<std::string, float> timings;
     std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> region_evt;
@@ -246,18 +248,23 @@ hipEvent_t get_evt(ev_handle* h) {
     return h->evt_pool[h->evt_next++];
 }
 struct KScope {   // wraps one kernel launch with events when profiling is on
-    ev_handle* h; int sid = -1; hipEvent_t a{}, b{}; hipStream_t st;
-    KScope(ev_handle* h_, const char* name, double flops, double bytes, hipStream_t s = nullptr) : h(h_), st(s ? s : h_->stream) {
+    ev_handle* h; int sid = -1; int rec = -1; hipEvent_t a{}, b{}; hipStream_t st;
+    KScope(ev_handle* h_, const char* name, double flops, double bytes, hipStream_t s = nullptr, const ConvGemmParams* g = nullptr)
+        : h(h_), st(s ? s : h_->stream) {
         if (!h->profiling) return;
         sid = stat_id(h, name);
         h->stats[sid].launches++; h->stats[sid].flops += flops; h->stats[sid].bytes += bytes;
+        LaunchRec r; r.name = name; r.flops = flops; r.bytes = bytes;
+        if (g) { r.M = g->M; r.N = g->N; r.K = g->K; r.taps = g->taps; r.dil = g->dil; }
+        h->launches.push_back(r);
+        rec = (int)h->launches.size() - 1;
         a = get_evt(h); b = get_evt(h);
         (void)hipEventRecord(a, st);
     }
     ~KScope() {
         if (sid < 0) return;
         (void)hipEventRecord(b, st);
-        h->pending.push_back({a, b, sid});
+        h->pending.push_back({a, b, sid, rec});
     }
 };
 void region_begin(ev_handle* h, const char* name) {
@@ -271,11 +278,16 @@ void region_end(ev_handle* h, const char* name) {
     (void)hipEventRecord(h->region_evt[name].second, h->stream);
 }
 void profiling_reset(ev_handle* h) {
-    h->stats.clear(); h->stat_idx.clear(); h->pending.clear(); h->evt_next = 0; h->timings.clear();
+    h->stats.clear(); h->stat_idx.clear(); h->pending.clear(); h->evt_next = 0; h->timings.clear(); h->launches.clear();
 }
 void profiling_collect(ev_handle* h) {
     if (!h->profiling) return;
-    for (auto& p : h->pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b); h->stats[p.stat].ms += ms; }
+    for (auto& p : h->pending) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        h->stats[p.stat].ms += ms;
+        if (p.rec >= 0 && p.rec < (int)h->launches.size()) h->launches[p.rec].ms = ms;
+    }
     h->pending.clear();
     for (auto& kv : h->region_evt) {
         float ms = 0;
@@ -303,7 +315,7 @@ int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_r
     const double flops = 2.0 * valid_rows * p.N * (double)p.K * p.taps;
     double bytes = valid_rows * ((double)p.K * es + (double)p.N * (p.out16 ? 2 : 0) + (double)p.N * (p.out32 ? 4 : 0)) +
                    (double)p.N * p.K * p.taps * es;
-    KScope ks(h, name, flops, bytes, st);
+    KScope ks(h, name, flops, bytes, st, &p);
     launch_conv_gemm(p, st ? st : h->stream);
     return 0;
 }
@@ -599,7 +611,8 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     memset(&rp, 0, sizeof rp);
                     rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = p.W; rp.M = p.M; rp.k = k; rp.dil = dil; rp.gmin = -lo2; rp.gmax = rows_out - lo2; rp.epi = p;
                     const double fl = 2.0 * 2.0 * valid_out * frac * cout * (double)cout * k;
-                    KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0, sj);
+                    ConvGemmParams shape = p; shape.dil = dil;
+                    KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0, sj, &shape);
                     if (cout == 32) launch_resblock_pair_c32(rp, sj);
                     else launch_resblock_pair_c64(rp, sj);
                 } else if (gemm(h, gname, p, valid_out * frac, sj)) return -1;
@@ -867,6 +880,15 @@ int ev_get_timing(ev_handle* h, const char* name, float* ms) {
     auto it = h->timings.find(name);
     if (it == h->timings.end()) return fail(h, "no timing named %s", name);
     *ms = it->second;
+    return 0;
+}
+int ev_launch_record_count(ev_handle* h) { return h ? (int)h->launches.size() : -1; }
+int ev_get_launch_record(ev_handle* h, int idx, ev_launch_record* out) {
+    if (!h || !out || idx < 0 || idx >= (int)h->launches.size()) return -1;
+    const LaunchRec& r = h->launches[idx];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", r.name.c_str());
+    out->M = r.M; out->N = r.N; out->K = r.K; out->taps = r.taps; out->dil = r.dil; out->ms = r.ms; out->flops = r.flops; out->bytes = r.bytes;
     return 0;
 }
 int ev_kernel_stat_count(ev_handle* h) { return h ? (int)h->stats.size() : -1; }

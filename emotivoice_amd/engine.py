@@ -261,6 +261,15 @@ class EVEngine:
                 out[name] = float(ms.value)
         return out
 
+    def launch_records(self) -> List[dict]:
+        """Per-launch records of the last profiled call (set_profiling(True)), in launch order."""
+        out = []
+        r = _ffi.ev_launch_record()
+        for i in range(self._lib.ev_launch_record_count(self._h)):
+            self._lib.ev_get_launch_record(self._h, i, C.byref(r))
+            out.append(dict(name=r.name.decode(), M=r.M, N=r.N, K=r.K, taps=r.taps, dil=r.dil, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))
+        return out
+
     def kernel_stats(self) -> List[dict]:
         out = []
         st = _ffi.ev_kernel_stat()

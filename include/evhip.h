@@ -205,6 +205,19 @@ typedef struct ev_kernel_stat {
 int ev_kernel_stat_count(ev_handle* h);
 int ev_get_kernel_stat(ev_handle* h, int idx, ev_kernel_stat* out);
 
+/* Per-LAUNCH records of the last profiled call, in launch order: kernel family, the GEMM / conv shape (M rows, N output channels,
+ * K input channels, taps, dilation; 0 for non-GEMM kernels), hipEvent duration and algorithmic FLOPs / bytes.  Lets a reader
+ * recompute TF/s and TB/s per layer (profiles/ r2_*_launches.json). */
+typedef struct ev_launch_record {
+    char name[48];
+    int32_t M, N, K, taps, dil;
+    float ms;
+    double flops;
+    double bytes;
+} ev_launch_record;
+int ev_launch_record_count(ev_handle* h);
+int ev_get_launch_record(ev_handle* h, int idx, ev_launch_record* out);
+
 #ifdef __cplusplus
 }
 #endif
