@@ -34,6 +34,9 @@ constexpr int GAP = 4;            // gap rows between utterances (token and fram
 constexpr int ROW_ALIGN = 256;    // row counts are padded to the largest GEMM M tile
 constexpr int PAD_ROWS = 64;      // readable slack rows before / after every activation buffer
 constexpr int MEL_PAD = 96;       // n_mels padded to a multiple of 32 (MFMA K granularity)
+constexpr size_t PIN_MAX_B = 1 << 16;                // utterances per call the pinned staging area is laid out for
+constexpr size_t PIN_FRAME = 4 * PIN_MAX_B * 4;      // byte offset of the frame-layout region (after the token-layout region)
+constexpr size_t PIN_BYTES = PIN_FRAME + 2 * PIN_MAX_B * 4;
 
 thread_local std::string g_create_error;
 
@@ -73,6 +76,7 @@ struct ev_handle {
     // persistent outputs (host side)
     std::vector<int32_t> mel_lens; std::vector<int64_t> mel_offs;
     std::vector<int64_t> forced_dur;
+    std::vector<int64_t> pack_host[8]; std::vector<int32_t> pack_rows[8]; int pack_slot = 0;   // host staging of pack_level (kept alive, no sync)
     // layout of the last call
     int B = 0, total_tokens = 0; int64_t total_frames = 0;
     int Rt = 0, Rf = 0;
@@ -82,7 +86,7 @@ struct ev_handle {
     // device maps (inside the arena)
     int32_t *d_tok_seq = nullptr, *d_tok_pos = nullptr, *d_tok_off = nullptr, *d_tok_len = nullptr, *d_cu = nullptr;
     uint8_t* d_tok_valid = nullptr;
-    int32_t *d_frm_seq = nullptr, *d_frm_pos = nullptr, *d_frm_off = nullptr, *d_mel_len = nullptr;
+    int32_t *d_frm_seq = nullptr, *d_frm_pos = nullptr, *d_frm_off = nullptr, *d_mel_len = nullptr, *d_frm_len = nullptr;
     uint8_t* d_frm_valid = nullptr;
     // profiling
     bool profiling = false;
@@ -683,19 +687,15 @@ int build_frame_layout(ev_handle* h, ArenaPlan& ap, bool dry, int B) {
     const int Rf = (int)align_up((size_t)rows, ROW_ALIGN);
     h->d_frm_seq = ap.arr<int32_t>(Rf); h->d_frm_pos = ap.arr<int32_t>(Rf); h->d_frm_valid = ap.arr<uint8_t>(Rf);
     h->d_frm_off = ap.arr<int32_t>(B);
+    h->d_frm_len = ap.arr<int32_t>(B);
     if (!dry) {
-        char* st = h->pinned;   // caller reserved >= Rf*9 + B*4 bytes
-        int32_t* seq = (int32_t*)st; int32_t* pos = seq + Rf; int32_t* off = pos + Rf; uint8_t* valid = (uint8_t*)(off + B);
-        for (int r = 0; r < Rf; ++r) { seq[r] = -1; pos[r] = 0; valid[r] = 0; }
-        for (int b = 0; b < B; ++b) {
-            off[b] = h->frm_off[b];
-            for (int t = 0; t < h->mel_lens[b]; ++t) { const int r = h->frm_off[b] + t; seq[r] = b; pos[r] = t; valid[r] = 1; }
-        }
-        (void)hipMemcpyAsync(h->d_frm_seq, seq, (size_t)Rf * 4, hipMemcpyHostToDevice, h->stream);
-        (void)hipMemcpyAsync(h->d_frm_pos, pos, (size_t)Rf * 4, hipMemcpyHostToDevice, h->stream);
+        // only the B first-row offsets and lengths travel; the per-row maps are built on the device (no host loop over rows, no
+        // synchronisation: the pinned frame region [PIN_FRAME, ...) is not rewritten before the call's final synchronisation)
+        int32_t* off = (int32_t*)(h->pinned + PIN_FRAME); int32_t* len = off + B;
+        for (int b = 0; b < B; ++b) { off[b] = h->frm_off[b]; len[b] = h->mel_lens[b]; }
         (void)hipMemcpyAsync(h->d_frm_off, off, (size_t)B * 4, hipMemcpyHostToDevice, h->stream);
-        (void)hipMemcpyAsync(h->d_frm_valid, valid, (size_t)Rf, hipMemcpyHostToDevice, h->stream);
-        (void)hipStreamSynchronize(h->stream);   // the pinned staging area is re-used
+        (void)hipMemcpyAsync(h->d_frm_len, len, (size_t)B * 4, hipMemcpyHostToDevice, h->stream);
+        launch_row_maps(h->d_frm_off, h->d_frm_len, B, h->d_frm_seq, h->d_frm_pos, h->d_frm_valid, Rf, h->stream);
     }
     return Rf;
 }
@@ -703,9 +703,14 @@ int build_frame_layout(ev_handle* h, ArenaPlan& ap, bool dry, int B) {
 // gather per-utterance valid rows of a row-layout buffer into a packed fp32 device buffer
 int pack_level(ev_handle* h, const void* src, int dtype, int ld, int C, int level_shift, bool token_level, float* dst, int64_t* d_scratch3B) {
     const int B = h->B;
-    std::vector<int64_t> host(3 * (size_t)B);
+    // host staging lives in the handle (a ring of slots: one call packs at most 4 levels + the stage taps of a test) so that no
+    // synchronisation is needed for it to outlive the asynchronous copies
+    h->pack_slot = (h->pack_slot + 1) % 8;
+    std::vector<int64_t>& host = h->pack_host[h->pack_slot];
+    std::vector<int32_t>& rows32 = h->pack_rows[h->pack_slot];
+    host.assign(3 * (size_t)B, 0);
+    rows32.assign(B, 0);
     int64_t max_rows = 0, out = 0;
-    std::vector<int32_t> rows32(B);
     for (int b = 0; b < B; ++b) {
         const int64_t n = token_level ? h->tok_len[b] : ((int64_t)h->mel_lens[b] << level_shift);
         host[b] = token_level ? h->tok_off[b] : ((int64_t)h->frm_off[b] << level_shift);
@@ -717,7 +722,6 @@ int pack_level(ev_handle* h, const void* src, int dtype, int ld, int C, int leve
     HIPCHK(h, hipMemcpyAsync(d_row_off, host.data(), (size_t)2 * B * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_rows, rows32.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     launch_pack_rows(src, dtype, ld, C, d_row_off, d_out_off, d_rows, B, max_rows, dst, h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
     return 0;
 }
 
@@ -944,7 +948,8 @@ int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32
     Buf mel16; VocBufs vb; float* d_wav = nullptr; int16_t* d_i16 = nullptr; int64_t* d_scr = nullptr; int64_t* d_eoff = nullptr;
     void* d_melin = nullptr; int Rf = 0;
     { int64_t rows = GAP; for (int b = 0; b < B; ++b) rows += mel_lens[b] + GAP; Rf = (int)align_up((size_t)rows, ROW_ALIGN); }
-    if (pinned_reserve(h, (size_t)Rf * 9 + (size_t)B * 16 + 1024)) return -1;
+    if ((size_t)B > PIN_MAX_B) return fail(h, "at most %zu utterances per call", PIN_MAX_B);
+    if (pinned_reserve(h, PIN_BYTES)) return -1;
     size_t need = 0;
     for (int pass = 0; pass < 2; ++pass) {
         ArenaPlan ap{h, 1, pass == 0};
@@ -1045,21 +1050,19 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         if (keep) { tb.ltaps.resize(c.enc_layers); for (auto& b : tb.ltaps) b = ap.rows(Rt, C, 4); tb.tokemb_tap = ap.rows(Rt, C, 4); }
         tok_arena_end = ap.off;
     }
-    // host-side token maps
-    if (pinned_reserve(h, (size_t)Rt * 9 + (size_t)B * 64 + 1024)) return -1;
+    // token layout: B offsets / lengths / cu_seqlens through the pinned token region, per-row maps built on the device
+    if ((size_t)B > PIN_MAX_B) return fail(h, "ev_synthesize: at most %zu utterances per call", PIN_MAX_B);
+    if (pinned_reserve(h, PIN_BYTES)) return -1;
     {
-        int32_t* seq = (int32_t*)h->pinned; int32_t* pos = seq + Rt; int32_t* off = pos + Rt; int32_t* len = off + B; uint8_t* valid = (uint8_t*)(len + B);
-        for (int r = 0; r < Rt; ++r) { seq[r] = -1; pos[r] = 0; valid[r] = 0; }
-        for (int b = 0; b < B; ++b) {
-            off[b] = h->tok_off[b]; len[b] = h->tok_len[b];
-            for (int j = 0; j < h->tok_len[b]; ++j) { const int r = h->tok_off[b] + j; seq[r] = b; pos[r] = j; valid[r] = 1; }
-        }
-        HIPCHK(h, hipMemcpyAsync(h->d_tok_seq, seq, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_tok_pos, pos, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
+        int32_t* off = (int32_t*)h->pinned; int32_t* len = off + B; int32_t* pcu = len + B;
+        for (int b = 0; b < B; ++b) { off[b] = h->tok_off[b]; len[b] = h->tok_len[b]; }
+        memcpy(pcu, cu, (size_t)(B + 1) * 4);
         HIPCHK(h, hipMemcpyAsync(h->d_tok_off, off, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_tok_len, len, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_tok_valid, valid, (size_t)Rt, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_cu, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_cu, pcu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        launch_row_maps(h->d_tok_off, h->d_tok_len, B, h->d_tok_seq, h->d_tok_pos, h->d_tok_valid, Rt, h->stream);
+        // caller-owned inputs: borrowed for the duration of the call (host pointers are pageable: the runtime stages them before
+        // hipMemcpyAsync returns; device pointers are read in stream order)
         const hipMemcpyKind kind = dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         HIPCHK(h, hipMemcpyAsync(tb.d_ling, ling, (size_t)NT * 8, kind, h->stream));
         HIPCHK(h, hipMemcpyAsync(tb.d_spk, speaker, (size_t)B * 8, kind, h->stream));
@@ -1067,7 +1070,6 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         HIPCHK(h, hipMemcpyAsync(tb.d_content, content, (size_t)B * c.bert_dim * 4, kind, h->stream));
         if (flags & EV_FLAG_FORCED_DURATIONS)
             HIPCHK(h, hipMemcpyAsync(tb.d_forced, h->forced_dur.data(), (size_t)NT * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     region_begin(h, "total");
     region_begin(h, "am");
@@ -1137,7 +1139,8 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     int Rf = 0;
     const size_t esd = dec_prec == DT_F16 ? 2 : 4;
     { int64_t r = GAP; for (int b = 0; b < B; ++b) r += h->mel_lens[b] + GAP; Rf = (int)align_up((size_t)r, ROW_ALIGN); }
-    if (pinned_reserve(h, (size_t)Rf * 9 + (size_t)B * 16 + 1024)) return -1;
+    if ((size_t)B > PIN_MAX_B) return fail(h, "at most %zu utterances per call", PIN_MAX_B);
+    if (pinned_reserve(h, PIN_BYTES)) return -1;
     size_t frm_need = 0;
     for (int pass = 0; pass < 2; ++pass) {
         ArenaPlan ap{h, 1, pass == 0};
@@ -1272,24 +1275,19 @@ int ev_style_embed(ev_handle* h, int B, const int64_t* input_ids, const int64_t*
         x = ap.rows(Rt, H, 4); t = ap.rows(Rt, H, 4); qkv = ap.rows(Rt, 3 * H, 4); ctx = ap.rows(Rt, H, 4); ffn = ap.rows(Rt, I, 4);
         need = ap.off;
     }
-    if (pinned_reserve(h, (size_t)Rt * 9 + (size_t)B * 64 + 1024)) return -1;
+    if ((size_t)B > PIN_MAX_B) return fail(h, "ev_style_embed: at most %zu texts per call", PIN_MAX_B);
+    if (pinned_reserve(h, PIN_BYTES)) return -1;
     {
-        int32_t* seq = (int32_t*)h->pinned; int32_t* pos = seq + Rt; int32_t* poff = pos + Rt; int32_t* plen = poff + B; uint8_t* valid = (uint8_t*)(plen + B);
-        for (int r = 0; r < Rt; ++r) { seq[r] = -1; pos[r] = 0; valid[r] = 0; }
-        for (int b = 0; b < B; ++b) {
-            poff[b] = off[b]; plen[b] = len[b];
-            for (int j = 0; j < len[b]; ++j) { const int r = off[b] + j; seq[r] = b; pos[r] = j; valid[r] = 1; }
-        }
-        HIPCHK(h, hipMemcpyAsync(d_seq, seq, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(d_pos, pos, (size_t)Rt * 4, hipMemcpyHostToDevice, h->stream));
+        int32_t* poff = (int32_t*)h->pinned; int32_t* plen = poff + B; int32_t* pcu = plen + B;
+        for (int b = 0; b < B; ++b) { poff[b] = off[b]; plen[b] = len[b]; }
+        memcpy(pcu, cu, (size_t)(B + 1) * 4);
         HIPCHK(h, hipMemcpyAsync(d_off, poff, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(d_len, plen, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(d_valid, valid, (size_t)Rt, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(d_cu, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_cu, pcu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        launch_row_maps(d_off, d_len, B, d_seq, d_pos, d_valid, Rt, h->stream);
         const hipMemcpyKind kind = dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         HIPCHK(h, hipMemcpyAsync(d_ids, input_ids, (size_t)NT * 8, kind, h->stream));
         if (token_type_ids) HIPCHK(h, hipMemcpyAsync(d_tt, token_type_ids, (size_t)NT * 8, kind, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     WPTR(wword, float, "sb.emb.word"); WPTR(wpos, float, "sb.emb.pos"); WPTR(wtype, float, "sb.emb.type");
     WPTR(eg, float, "sb.emb.ln.g"); WPTR(eb, float, "sb.emb.ln.b");
@@ -1367,6 +1365,7 @@ int64_t ev_get_stage(ev_handle* h, const char* name, void* host_dst, size_t cap)
     HIPCHK(h, hipMalloc((void**)&d_tmp, need));
     HIPCHK(h, hipMalloc((void**)&d_scr, (3 * (size_t)h->B + 8) * 8));
     int rc = pack_level(h, t.ptr, t.dtype, t.ld, t.C, t.shift, t.level == 0, d_tmp, d_scr);
+    if (rc == 0 && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, "ev_get_stage: gather failed");
     if (rc == 0 && hipMemcpy(host_dst, d_tmp, need, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, "ev_get_stage: D2H failed");
     (void)hipFree(d_tmp); (void)hipFree(d_scr);
     return rc ? -1 : (int64_t)need;

@@ -28,6 +28,14 @@
 
 #include "ev_kernels.h"
 
+// No implicit FMA contraction in this file.  The engine promises results that do not depend on how an utterance is batched
+// (tests: test_batch_invariance_bit_exact), but which kernel / tile / epilogue variant a GEMM takes DOES depend on the batch's
+// row count.  All variants accumulate the MFMA products in the same order; what differed (found by the split-precision mode's
+// bit-exact test) was hipcc contracting "(v + res) * scale + acc" into an fma in the straight-line epilogue and not in the
+// branchy one.  With contraction off every epilogue rounds each operation separately, whatever the code shape; explicit fmaf()
+// calls (gelu_fast) are unaffected.
+#pragma clang fp contract(off)
+
 namespace ev {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -860,9 +868,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const ConvGemmPara
     constexpr int XBUF = SLABR * 64, WBUF = BN * 64;
     static_assert(WM * WN == 8 && SLABR * 4 == XCH * 512 && SLABR >= BM + MAX_SPAN, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Xh = smem;                    // [2][SLABR][64]  hi parts
-    char* Xl = Xh + 2 * XBUF;           // [2][SLABR][64]  lo parts (scaled by 2^11)
-    char* Wh = Xl + 2 * XBUF;           // [2][BN][64]
+    // a single K-chunk (K = 32: the C = 32 layers of the generator's last stage) needs one slab buffer, not two: 57 KB instead of
+    // 106 KB at BN = 32, i.e. two blocks per CU, so that one block's slab load (the whole of its HBM latency: there is no next
+    // chunk to prefetch) overlaps the other's taps.  The launcher sizes the dynamic LDS the same way (x3_lds_bytes).
+    const int nxb = (p.K > 32) ? 2 : 1;
+    char* Xh = smem;                    // [nxb][SLABR][64]  hi parts
+    char* Xl = Xh + nxb * XBUF;         // [nxb][SLABR][64]  lo parts (scaled by 2^11)
+    char* Wh = Xl + nxb * XBUF;         // [2][BN][64]
     char* Wl = Wh + 2 * WBUF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave / WN, wc = wave % WN;
@@ -1024,13 +1036,16 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const ConvGemmPara
 }
 
 template <int BN>
-static constexpr size_t x3_lds_bytes() { return 4 * (size_t)384 * 64 + 4 * (size_t)BN * 64; }
+static constexpr size_t x3_lds_bytes(int nxb = 2) { return 2 * (size_t)nxb * 384 * 64 + 4 * (size_t)BN * 64; }
 
 template <int BN, int WM, int WN, int EPI>
 static void launch_x3_cfg(const ConvGemmParams& p, hipStream_t s) {
-    static_assert(8 * 32 * ((BN / WN) * 4 + 16) <= x3_lds_bytes<BN>(), "epilogue scratch aliases the staging buffers");
+    static_assert(8 * 32 * ((BN / WN) * 4 + 16) <= x3_lds_bytes<BN>(2), "epilogue scratch aliases the staging buffers");
     const int grid = (p.M / 256) * (p.N / BN);
-    hipLaunchKernelGGL((conv_gemm_x3_kernel<BN, WM, WN, EPI>), dim3(grid), dim3(512), x3_lds_bytes<BN>(), s, p);
+    size_t lds = x3_lds_bytes<BN>(p.K > 32 ? 2 : 1);
+    const size_t epi = 8 * 32 * (size_t)((BN / WN) * 4 + 16);          // the transposed epilogue re-uses the staging buffers
+    if (epi > lds) lds = epi;
+    hipLaunchKernelGGL((conv_gemm_x3_kernel<BN, WM, WN, EPI>), dim3(grid), dim3(512), lds, s, p);
 }
 template <int EPI>
 static void launch_x3_epi(const ConvGemmParams& p, hipStream_t s) {
@@ -1042,9 +1057,9 @@ static void launch_x3_epi(const ConvGemmParams& p, hipStream_t s) {
 template <int EPI>
 static hipError_t x3_attr_epi() {
     hipError_t e = hipSuccess, r;
-    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<128, 4, 2, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<128>()); if (r != hipSuccess) e = r;
-    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<64, 8, 1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<64>()); if (r != hipSuccess) e = r;
-    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<32, 8, 1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<32>()); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<128, 4, 2, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<128>(2)); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<64, 8, 1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<64>(2)); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<32, 8, 1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<32>(2)); if (r != hipSuccess) e = r;
     return e;
 }
 static hipError_t x3_set_attributes() {
@@ -1087,10 +1102,11 @@ static void launch_split(const ConvGemmParams& p, hipStream_t s) {
     // each: the first-generation kernel's 128 x 64 tiles at two 4-wave blocks per CU give 4x the blocks (measured: encoder GEMMs
     // 1.40 ms vs 1.81 ms, predictors 0.31 vs 0.54 ms)
     const long tiles_x3 = (long)(p.M / 256) * (p.N % 128 == 0 ? p.N / 128 : (p.N % 64 == 0 ? p.N / 64 : p.N / 32));
-    if (old_kernel || (tiles_x3 < 512 && p.N % 64 == 0)) {
-        if (plain && !p.acc32 && p.act != ACT_LRELU && !p.res && !rare_act) return launch_split_epi<EPI_O32>(p, s);
-        if (plain && !p.acc32 && p.act != ACT_LRELU && !p.res && rare_act) return launch_split_epi<EPI_RARE_ACT | EPI_O32>(p, s);
-        if (plain && !p.acc32 && p.act != ACT_LRELU && res32 && !rare_act) return launch_split_epi<EPI_RES32 | EPI_O32>(p, s);
+    if (old_kernel || (tiles_x3 < 512 && p.N % 64 == 0)) {      // (same epilogue variant as the second-generation kernel would take)
+        if (plain && !p.acc32 && !p.res && !rare_act) return launch_split_epi<EPI_O32>(p, s);
+        if (plain && !p.acc32 && !p.res && rare_act) return launch_split_epi<EPI_RARE_ACT | EPI_O32>(p, s);
+        if (plain && !p.acc32 && res32 && !rare_act) return launch_split_epi<EPI_RES32 | EPI_O32>(p, s);
+        if (plain && p.acc32 && res32 && !rare_act) return launch_split_epi<EPI_RES32 | EPI_ACC32 | EPI_O32>(p, s);
         return launch_split_epi<EPI_GENERIC>(p, s);
     }
     if (plain && !p.acc32 && !p.res && !rare_act) return launch_x3_epi<EPI_O32>(p, s);

@@ -136,6 +136,8 @@ void launch_pack_rows(const void* src, int dtype, int ld, int C, const int64_t* 
 // which auto-extends its table the same way for inputs longer than max_len)
 void launch_pe_extend(float* pe, const float* div, int row0, int row1, int C, hipStream_t s);
 void launch_wav_to_i16(const float* wav, int16_t* out, int64_t n, hipStream_t s);
+// gap-layout row maps on the device: seq[r] = utterance of row r (-1 in gaps), pos[r] = position inside it, valid[r]
+void launch_row_maps(const int32_t* off, const int32_t* len, int B, int32_t* seq, int32_t* pos, uint8_t* valid, int rows, hipStream_t s);
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 
 }  // namespace ev

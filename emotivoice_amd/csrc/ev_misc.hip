@@ -877,6 +877,27 @@ void launch_conv_post(const void* x, int is_f32, int ldx, const float* w, float 
                            pre_slope, row_valid, valid_shift, wav_rows, rows);
 }
 
+// ------------------------------------------------------------------ row maps of the gap layout
+// rows -> (utterance, position, valid) from the per-utterance first row / length: one thread per row, binary search over the
+// utterance offsets.  Replaces O(rows) host loops + three H2D copies + a stream synchronisation per call.
+__global__ __launch_bounds__(256) void row_maps_kernel(const int32_t* off, const int32_t* len, int B, int32_t* seq, int32_t* pos,
+                                                       uint8_t* valid, int rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    int lo = 0, hi = B - 1, b = -1;
+    while (lo <= hi) {              // last utterance whose first row is <= r
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= r) { b = mid; lo = mid + 1; } else hi = mid - 1;
+    }
+    const bool in = b >= 0 && r < off[b] + len[b];
+    seq[r] = in ? b : -1;
+    pos[r] = in ? r - off[b] : 0;
+    valid[r] = in ? 1 : 0;
+}
+void launch_row_maps(const int32_t* off, const int32_t* len, int B, int32_t* seq, int32_t* pos, uint8_t* valid, int rows, hipStream_t s) {
+    hipLaunchKernelGGL(row_maps_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, off, len, B, seq, pos, valid, rows);
+}
+
 // ------------------------------------------------------------------ packing helpers
 __global__ __launch_bounds__(256) void pack_rows_kernel(const void* src, int dtype, int ld, int C, const int64_t* seq_row_off,
                                                         const int64_t* seq_out_off, const int32_t* seq_rows, float* dst) {

@@ -154,9 +154,11 @@ def main():
         for name, v in family_sums(ps, cs).items():
             d = dict(v)
             if v.get("GRBM_GUI_ACTIVE"):
-                # SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles summed over the 4 SIMDs of every CU (MI355X_MICROARCH.md, cycle table):
-                # fraction of the chip's matrix-pipe cycles = busy / (GPU-active cycles x 256 CUs x 4 SIMDs)
-                d["mfma_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 256 * 4)
+                # SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over every SIMD of the chip (measured: exactly 16.0
+                # per v_mfma_f32_16x16x32_f16 on a launch of known MFMA count); GRBM_GUI_ACTIVE is the sum of the 8 XCDs' active
+                # cycles (measured 15.4 cycles / ns = 8 x 1.93 GHz).  Fraction of all matrix-pipe cycles that were busy =
+                # busy / (per-XCD active cycles x 256 CUs x 4 SIMDs) -- rocprofv3's own MfmaUtil expression.
+                d["mfma_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
             if v.get("SQ_BUSY_CU_CYCLES"):
                 d["mfma_busy_over_busy_cu_cycles"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CU_CYCLES"]
             if v.get("SQ_WAVE_CYCLES"):
