@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & (EPI_ACC32 | EP
     int woff[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) woff[a] = swz(wc * TC + a * 16 + fr, fq);
+    const bool prio_ = (p.reserved0 & 1) != 0;
 
 #define EV_COMPUTE(WBUFSEL, KC, TAP)                                                                           \
     {                                                                                                          \
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & (EPI_ACC32 | EP
         uint4 xf[MT], wf[NT];                                                                                  \
         _Pragma("unroll") for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xb_ + b * 16 * 64); \
         _Pragma("unroll") for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(Wb_ + woff[a]);  \
+        if (prio_) __builtin_amdgcn_s_setprio(1);      /* tuning switch (ConvGemmParams::reserved0 bit 0, tools/bench_gemm.py) */ \
         _Pragma("unroll") for (int a = 0; a < NT; ++a) {                                                       \
             _Pragma("unroll") for (int b = 0; b < MT; ++b) {                                                   \
                 if constexpr (ES == 2) {                                                                       \
@@ -538,6 +540,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & (EPI_ACC32 | EP
                 }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
+        if (prio_) __builtin_amdgcn_s_setprio(0);                                                              \
     }
 
     // prologue: X(0), W(step 0) -> LDS; W(step 1) -> registers

@@ -64,6 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--dbg", default="0", help="comma list of ConvGemmParams::reserved0 tuning switches to compare (bit 0: s_setprio around the MFMA cluster)")
     args = ap.parse_args()
     lib = _ffi.lib()
     for name in args.shapes.split(","):
@@ -95,7 +96,8 @@ def main():
         else:
             d.out32 = out.data_ptr()
         d.ldo = N
-        for dbg in [0]:
+        for dbg in [int(x) for x in args.dbg.split(",")]:
+            d.reserved0 = dbg
             for _ in range(2):
                 lib.ev_op_conv_gemm(C.byref(d), None)
             torch.cuda.synchronize()
