@@ -667,7 +667,14 @@ static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
 }
 
 template <typename TIn>
-static void launch_dt(const ConvGemmParams& p, hipStream_t s) {
+static void launch_dt(const ConvGemmParams& p_in, hipStream_t s) {
+    // s_setprio(1) around a step's MFMA cluster: the two blocks of a CU are not in lockstep, and raising the priority of the wave
+    // that is in its matrix phase over its SIMD partner's staging / LDS phase measured +4 % on the C = 256 layers (s0 k = 11:
+    // 998 -> 1039 TF/s), +1-4 % on the up-convs and decoder GEMMs, nothing at C = 128 / k >= 7 and -1...-4 % on the HBM-bound
+    // C = 128 / k = 3 layers (tools/bench_gemm.py --dbg 0,1,0,1, profiles/r2_e_gemm_setprio.txt): on for N >= 256 only.
+    ConvGemmParams p = p_in;
+    static const char* prio_env = getenv("EV_GEMM_PRIO");            // "0" / "1": A/B override
+    if (prio_env ? prio_env[0] == '1' : p.N >= 256) p.reserved0 |= 1;
     if (p.N % 128 == 0) {
         // 256-row tiles halve the weight-tile traffic per FLOP and the barrier count per MFMA; since the epilogue stopped scaling
         // with vmcnt round trips they win on every shape measured (tools/bench_gemm.py, EV_GEMM_TILE=128/256), so 128-row
