@@ -339,8 +339,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
     {                                                                                                    \
         *reinterpret_cast<uint4*>((KB_) + (KEY) * KP + (PART) * 16) = KR;                                \
         const h8 hv_ = *reinterpret_cast<const h8*>(&VR);                                                \
+        /* V^T rows 8 apart are 1152 bytes = 288 dwords = 0 mod 32 banks apart: the six parts of one key hit ONE bank (the 61 % */ \
+        /* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of profiles/r2_d).  The key index is XOR-ed with 4 * (row >> 3): banks 0, 2, ... 10; */ \
+        /* the 4-key groups the P.V fragment reads stay contiguous (the reads apply the same XOR). */ \
         _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                    \
-            *reinterpret_cast<_Float16*>((VB_) + ((PART) * 8 + e) * VP + (KEY) * 2) = hv_[e];            \
+            *reinterpret_cast<_Float16*>((VB_) + ((PART) * 8 + e) * VP + (((KEY) ^ ((PART) << 2)) * 2)) = hv_[e]; \
     }
 #define EV_AT_SSTORE(BUF)                                                                                \
     {                                                                                                    \
@@ -423,9 +426,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt) {
-                const char* vp = Vb + (dt * 16 + fr) * VP + (kb * 32 + 4 * fg) * 2;
-                const h4 lo = *reinterpret_cast<const h4*>(vp);
-                const h4 hi = *reinterpret_cast<const h4*>(vp + 32);
+                const int vrow = dt * 16 + fr, vx = (vrow >> 3) << 2;          // the staging XOR (see EV_AT_SSTORE1)
+                const char* vp = Vb + vrow * VP;
+                const h4 lo = *reinterpret_cast<const h4*>(vp + (((kb * 32 + 4 * fg) ^ vx) * 2));
+                const h4 hi = *reinterpret_cast<const h4*>(vp + (((kb * 32 + 16 + 4 * fg) ^ vx) * 2));
                 const h8 va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                 for (int nq = 0; nq < 2; ++nq) o[nq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[nq][kb], o[nq][dt], 0, 0, 0);

@@ -61,3 +61,43 @@ def test_no_cpu_fallback_without_gpu():
     from emotivoice_amd.engine import EVEngine, EVError
     with pytest.raises(EVError, match="no HIP device|no CPU fallback"):
         EVEngine()
+
+
+def test_ev_create_rejects_shapes_the_kernels_do_not_build():
+    """Config validation happens before any device is touched, so it is testable without a GPU: shapes the kernels would silently
+    mishandle must be refused with a message, not discovered as garbage audio."""
+    lib = _ffi.lib()
+
+    def create(**kw):
+        cfg = _ffi.ev_config()
+        lib.ev_default_config(C.byref(cfg))
+        for k, v in kw.items():
+            if isinstance(v, (list, tuple)):
+                for i, x in enumerate(v):
+                    getattr(cfg, k)[i] = x
+            else:
+                setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.ev_create(0, C.byref(cfg), C.byref(h))
+        msg = lib.ev_last_error(None).decode()
+        if rc == 0:
+            lib.ev_destroy(h)
+        return rc, msg
+
+    for kw, needle in ((dict(up_init_ch=1024), "upsample_initial_channel"), (dict(ffn_kernel=11), "conv kernels"),
+                       (dict(var_embed_kernel=13), "conv kernels"), (dict(rb_kernels=[3, 7, 15]), "ResBlock kernel"),
+                       (dict(vocoder_precision=1), "vocoder_precision"), (dict(decoder_precision=7), "decoder_precision"),
+                       (dict(n_rb=5), "generator layout"), (dict(abi_version=99), "abi_version")):
+        rc, msg = create(**kw)
+        assert rc != 0 and needle in msg, (kw, msg)
+
+
+def test_precision_names_resolve():
+    from emotivoice_amd.engine import resolve_precision
+    assert resolve_precision(None, None, None) == ("f16", "f16")
+    assert resolve_precision("fast", None, None) == ("f16", "f16")
+    assert resolve_precision("strict", None, None) == ("x3", "x3")
+    assert resolve_precision("strict", "f32", None) == ("f32", "x3")
+    assert resolve_precision(None, None, "x3") == ("f16", "x3")
+    with pytest.raises(ValueError):
+        resolve_precision("fastest", None, None)
