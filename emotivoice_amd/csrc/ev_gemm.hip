@@ -422,8 +422,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 // hipcc spill the prefetch registers to scratch inside the loop).
 __device__ __forceinline__ int swz(int row, int part) { return row * 64 + ((part ^ ((row >> 1) & 3)) << 4); }
 
+#ifdef EV_LB3        // tuning variant (build.py --variant lb3 EV_LB3): 3 waves / SIMD also for the MRF-epilogue instantiations of the small tiles
+#define EV_GEMM_MIN_WAVES(BM, BN, EPI) (((BM) * (BN) > 128 * 128) ? 2 : 3)
+#else
+#define EV_GEMM_MIN_WAVES(BM, BN, EPI) (((BM) * (BN) > 128 * 128 || ((EPI) & (EPI_ACC32 | EPI_ADD16))) ? 2 : 3)
+#endif
 template <typename TIn, int BM, int BN, int WT, int WC, int EPI>
-__global__ __launch_bounds__(256, (BM * BN > 128 * 128 || (EPI & (EPI_ACC32 | EPI_ADD16))) ? 2 : 3) void conv_gemm_kernel(const ConvGemmParams p EV_TRACE_ARG) {
+__global__ __launch_bounds__(256, EV_GEMM_MIN_WAVES(BM, BN, EPI)) void conv_gemm_kernel(const ConvGemmParams p EV_TRACE_ARG) {
     constexpr int ES = sizeof(TIn);
     constexpr int TT = BM / WT, TC = BN / WC, MT = TT / 16, NT = TC / 16;
     constexpr int SLAB = BM + MAX_SPAN;              // rows staged per K-chunk (>= BM + (taps-1)*dil, multiple of 64)

@@ -28,6 +28,9 @@ SHAPES = {
     "s2_k3": (0, RF * 128, 64, 64, 3, 1, False, True),
     "s2_k11": (0, RF * 128, 64, 64, 11, 5, False, True),
     "s2_k11_res": (0, RF * 128, 64, 64, 11, 1, True, False),
+    "s1_k11_mrf": (0, RF * 64, 128, 128, 11, 1, "mrf", False),     # last conv of a stage: fp16 residual + two fp16 MRF addends + post leaky-relu
+    "s2_k11_mrf": (0, RF * 128, 64, 64, 11, 1, "mrf", False),
+    "s2_k7_res": (0, RF * 128, 64, 64, 7, 1, True, False),
     "s3_k3": (0, RF * 256, 32, 32, 3, 1, False, True),
     "s3_k11": (0, RF * 256, 32, 32, 11, 5, False, True),
     "s3_k11_res": (0, RF * 256, 32, 32, 11, 1, True, False),
@@ -91,6 +94,10 @@ def main():
             d.pro_lrelu, d.pro_slope, d.act, d.act_slope = 1, 0.1, 3, 0.1
         if r is not None:
             d.res, d.res_dtype, d.ldres = r.data_ptr(), (0 if dtype == 0 else 1), N
+        if res == "mrf":
+            ma, mb = torch.randn(M, N, device="cuda").half(), torch.randn(M, N, device="cuda").half()
+            d.add16_a, d.add16_b, d.ldadd = ma.data_ptr(), mb.data_ptr(), N
+            d.out_scale, d.post_lrelu, d.post_slope = 1.0 / 3.0, 1, 0.1
         if dtype == 0:
             d.out16 = out.data_ptr()
         else:
