@@ -422,11 +422,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 // hipcc spill the prefetch registers to scratch inside the loop).
 __device__ __forceinline__ int swz(int row, int part) { return row * 64 + ((part ^ ((row >> 1) & 3)) << 4); }
 
-#ifdef EV_LB3        // tuning variant (build.py --variant lb3 EV_LB3): 3 waves / SIMD also for the MRF-epilogue instantiations of the small tiles
+// 2 waves / SIMD (<= 256 VGPRs) for the 256 x 128 tile, 3 for the smaller ones -- including their MRF-epilogue instantiations, which
+// round 1 had capped at 2: at 3 the RES16 | ADD16 | O16 epilogue spills 6 registers, outside the main loop, and the last conv of
+// stage 2 still gains 7 % (755 -> 705 us, profiles/r2_h_gemm_launch_bounds.txt).
 #define EV_GEMM_MIN_WAVES(BM, BN, EPI) (((BM) * (BN) > 128 * 128) ? 2 : 3)
-#else
-#define EV_GEMM_MIN_WAVES(BM, BN, EPI) (((BM) * (BN) > 128 * 128 || ((EPI) & (EPI_ACC32 | EPI_ADD16))) ? 2 : 3)
-#endif
 template <typename TIn, int BM, int BN, int WT, int WC, int EPI>
 __global__ __launch_bounds__(256, EV_GEMM_MIN_WAVES(BM, BN, EPI)) void conv_gemm_kernel(const ConvGemmParams p EV_TRACE_ARG) {
     constexpr int ES = sizeof(TIn);
