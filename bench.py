@@ -11,6 +11,7 @@ Workloads (BASELINE.json configs; seeded synthetic weights and inputs, nothing i
   ragged   -- configs[2]: batch 256, lengths 64 + (i * 7919 mod 449), speakers i mod 2000, "parity" weights (predicted durations
               vary: the length regulator's ragged path).
   vocoder  -- configs[4]: 128 pre-computed 80 x 1024 fp16 mels per GPU through ev_vocoder (1024 over 8 GPUs).
+  style    -- (not a BASELINE config) the SimBERT prompt / content encoder on the device: texts/s, CPU oracle beside it.
 One "step" = one pass of the rank's batch (all its sub-batches) with the inputs already resident in HBM.  N > 1: utterances are
 sharded (weak scaling, per-GPU work fixed); the only collective is the start-up broadcast of the packed weight blob over RCCL.
 Precision: "fast" = fp16 MFMA operands (the precision BASELINE.json names for these configs), "strict" = split precision
@@ -207,12 +208,55 @@ def roofline_block(eng, work, torch, strict):
     return roof, stages, kernels
 
 
+def bench_style(args, torch):
+    """--mode style: the SimBERT prompt / content encoder on the device (the reference runs it on the CPU, two calls
+    per utterance): texts of 64 tokens, pooled outputs per second, with the CPU oracle (the same BERT forward in torch fp32) beside it."""
+    from emotivoice_amd.engine import EVEngine
+    from emotivoice_amd.packer import pack_bert_state_dict
+    from emotivoice_amd.synthetic import synth_bert_state_dict, synth_token_ids
+    sd = synth_bert_state_dict(0)
+    blob, _, cfg = pack_bert_state_dict(sd)
+    eng = EVEngine(device_id=0)
+    eng.style_load(blob, cfg)
+    nb = args.batch or 64
+    ids = synth_token_ids(5, [64] * nb)
+    for _ in range(args.warmup):
+        eng.style_embed(ids)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.style_embed(ids)
+    dt = time.perf_counter() - t0
+    one = [ids[0]]
+    best = 1e9
+    for _ in range(10):
+        t1 = time.perf_counter(); eng.style_embed(one); best = min(best, time.perf_counter() - t1)
+    line = {"metric": "style_embeddings_per_sec", "value": round(nb * args.steps / dt, 1), "unit": "texts/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x3 (split precision, fp32-class)", "data": "synthetic",
+            "config": {"workload": "SimBERT (BERT-base 12 x 768) pooled_output of %d texts x 64 tokens per step, host ids in / host embeddings out" % nb},
+            "latency": {"one_text_64_tokens_ms": round(best * 1e3, 3)}, "roofline": None}
+    if args.cpu_utts > 0:
+        from oracle.bert_oracle import bert_pooled_output
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        bert_pooled_output(sd, ids[0])
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < 10.0 and n < 64:
+            bert_pooled_output(sd, ids[n % nb]); n += 1
+        cdt = time.perf_counter() - t0
+        line["cpu_baseline"] = dict(value=n / cdt, unit="texts/s", cores=min(os.cpu_count() or 1, 16), kind="port",
+                                    sample="%d texts x 64 tokens, one per call (the reference's call pattern), torch fp32, %.1f s" % (n, cdt))
+        ref = bert_pooled_output(sd, ids[0]).numpy()
+        line["parity_rel_l2_vs_oracle"] = float(np.linalg.norm(out[0] - ref) / np.linalg.norm(ref))
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", default="am_vocoder", choices=["am_vocoder", "ragged", "vocoder"])
+    ap.add_argument("--mode", default="am_vocoder", choices=["am_vocoder", "ragged", "vocoder", "style"])
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU per (sub-)batch (default: 32 / 256 / 128 by mode)")
     ap.add_argument("--sub-batches", type=int, default=0, help="am_vocoder: sub-batches per step (default 1 at N = 1, 8 at N > 1 = configs[3])")
     ap.add_argument("--phonemes", type=int, default=256)
@@ -237,6 +281,8 @@ def main():
     if args.sub_batches <= 0:
         args.sub_batches = 1 if world == 1 else 8
     torch.cuda.set_device(local_rank)
+    if args.mode == "style":
+        return bench_style(args, torch)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -16,9 +16,10 @@ Same command line, same directory layout, same flow:
   * wavs go to ``<output_directory>/<logdir>/test_audio/audio/<checkpoint>/<i+1>.wav`` (old files there are removed first,
     :86-89), 16-bit PCM at ``config.sampling_rate`` (:130-134).
 What differs: the generator is ``JETSGeneratorHIP`` (libevhip.so) and lines are synthesised in batches (``--batch``) with
-per-utterance B = 1 semantics instead of one call per line.  The SimBERT style encoder (:25-38,61-67) needs HF weights that are
-not part of this repo: embeddings come from ``--embeddings`` (an .npz with ``style`` / ``content`` rows, e.g. produced by the
-reference's StyleEncoder) or from the deterministic placeholder of text_io.HashStyleEmbedder.
+per-utterance B = 1 semantics instead of one call per line.  The SimBERT style encoder (:25-38,61-67) runs on the device
+(``StyleEncoderHIP``) when ``config.style_encoder_ckpt`` and the tokenizer files of ``config.bert_path`` exist on local disk; its
+weights are downloads that are not part of this repo, so otherwise embeddings come from ``--embeddings`` (an .npz with ``style`` /
+``content`` rows, e.g. produced by the reference's StyleEncoder) or from the deterministic placeholder of text_io.HashStyleEmbedder.
 Extra flags (not in the reference): ``--embeddings --batch --device --precision --synthetic-weights``.
 """
 from __future__ import annotations
@@ -47,6 +48,32 @@ def _load_config(config_folder: str):
     return Config()
 
 
+def _device_style_embedder(config, gen):
+    """The reference's get_style_embedding (:25-38) with the StyleEncoder on the device: needs the style-encoder checkpoint
+    (config.style_encoder_ckpt, :61-67) and the tokenizer files of config.bert_path on local disk (no hub access).  Returns a
+    ``text -> (768,)`` callable, or None when either is missing (the caller falls back to --embeddings / the placeholder)."""
+    ckpt, bert_path = getattr(config, "style_encoder_ckpt", None), getattr(config, "bert_path", None)
+    if not ckpt or not os.path.exists(ckpt) or not bert_path or not os.path.isdir(bert_path):
+        return None
+    try:
+        import torch
+        from transformers import AutoTokenizer
+
+        from .simbert import StyleEncoderHIP
+        tokenizer = AutoTokenizer.from_pretrained(bert_path, local_files_only=True)            # :83
+        model_ckpt = {k[7:]: v for k, v in torch.load(ckpt, map_location="cpu")["model"].items()}   # :63-66
+        enc = StyleEncoderHIP(config, engine=gen._ensure_engine()).load_state_dict(model_ckpt, strict=False).eval()
+    except Exception as e:                                  # noqa: BLE001 -- any missing piece means "no SimBERT available here"
+        print("style encoder not available (%s): using --embeddings / the placeholder" % e)
+        return None
+
+    def embed(text):
+        t = tokenizer([text], return_tensors="np")
+        out = enc(input_ids=t["input_ids"], token_type_ids=t["token_type_ids"], attention_mask=t["attention_mask"])
+        return np.asarray(out["pooled_output"], np.float32).squeeze()
+    return embed
+
+
 def synthesize_checkpoint(config, conf, checkpoint_path, out_dir, args, state_dict=None):
     token2id = read_table(config.token_list_path)            # :76-77
     speaker2id = read_table(config.speaker2id_path)          # :79-80
@@ -61,7 +88,9 @@ def synthesize_checkpoint(config, conf, checkpoint_path, out_dir, args, state_di
             os.remove(j)
     lines = read_text_file(args.test_file)                    # :96-102
     emb = np.load(args.embeddings) if args.embeddings else None
-    embedder = HashStyleEmbedder(gen.shapes.bert_dim)
+    embedder = _device_style_embedder(config, gen) if emb is None else None
+    if embedder is None:
+        embedder = HashStyleEmbedder(gen.shapes.bert_dim)
     todo = []
     for i, ln in enumerate(lines):
         if ln.speaker not in speaker2id:                      # silently skipped, :109-110

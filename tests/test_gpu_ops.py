@@ -456,3 +456,57 @@ def test_split_precision_generator_convs(lib, C_, k, dil):
     ref2[~vrow.cpu()] = 0
     o2 = call(False, False, True)
     assert _rel(o2.cpu().double(), ref2) < 3e-6, (C_, k, dil)
+
+
+@pytest.mark.parametrize("C_,N,k,dil", [(128, 128, 7, 3), (64, 64, 11, 5), (32, 32, 3, 1), (32, 32, 11, 5), (256, 512, 3, 1)])
+def test_split_precision_8_wave_kernel_large_m(lib, C_, N, k, dil):
+    """conv_gemm_x3_kernel (8 waves, 256-row tiles) is only selected from 512 tiles up (smaller GEMMs take the 128 x 64 kernel), so it
+    needs inputs of >= 131 072 rows to be exercised by an op test: all three BN configurations (128 / 64 / 32), the single-slab
+    K = 32 case, leaky-relu prologue + epilogue, fp32 residual + scale + fp32 accumulate-in (the in-place MRF sum: acc32 == out32),
+    and bit-identity with the small-tile kernel on the same rows (the engine's batch-invariance promise)."""
+    from emotivoice_amd import _ffi
+    torch.manual_seed(C_ + N + k)
+    M = 256 * 520 if N <= 128 else 256 * 136          # >= 512 tiles of 256 x BN
+    full = torch.randn(M + 2 * PAD, C_, device="cuda")
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x = full[PAD:PAD + M]
+    w = torch.randn(N, C_, k, device="cuda") / math.sqrt(C_ * k)
+    bias = torch.randn(N, device="cuda")
+    wg = w.permute(0, 2, 1).contiguous()
+    hi = wg.half()
+    lo = ((wg - hi.float()) * 2048.0).half()
+    res = torch.randn(M, N, device="cuda")
+    acc0 = torch.randn(M, N, device="cuda")
+
+    def call(rows, conv2):
+        d = _ffi.ev_conv_gemm_desc()
+        d.dtype, d.A, d.lda, d.W, d.W_lo = 2, x.data_ptr(), C_, hi.data_ptr(), lo.data_ptr()
+        d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), rows, N, C_, k, dil, (k - 1) // 2, 1.0
+        out = acc0[:rows].clone()
+        if conv2:
+            d.res, d.res_dtype, d.ldres, d.out_scale = res.data_ptr(), 1, N, 1.0 / 3.0
+            d.acc32, d.ldacc = out.data_ptr(), N          # in place, like the engine's running MRF sum
+        else:
+            d.pro_lrelu, d.pro_slope, d.act, d.act_slope = 1, 0.1, 3, 0.1
+        d.out32, d.ldo = out.data_ptr(), N
+        torch.cuda.synchronize()
+        assert lib.ev_op_conv_gemm(C.byref(d), None) == 0
+        torch.cuda.synchronize()
+        return out
+
+    sub = 256 * 8                                           # rows compared against the fp64 reference / the small-tile kernel
+    xin = full[:PAD + sub + PAD].double().cpu()
+    conv = lambda z: F.conv1d(z.t().unsqueeze(0), w.double().cpu(), bias.double().cpu(), dilation=dil).squeeze(0).t()  # noqa: E731
+    h = dil * (k - 1) // 2
+    for conv2 in (False, True):
+        big = call(M, conv2)
+        if conv2:
+            ref = (conv(xin)[PAD - h:PAD - h + sub] + res[:sub].double().cpu()) / 3.0 + acc0[:sub].double().cpu()
+        else:
+            ref = _lrelu(conv(_lrelu(xin, 0.1))[PAD - h:PAD - h + sub], 0.1)
+        assert _rel(big[:sub].cpu().double(), ref) < 3e-6, (C_, N, k, conv2)
+        small = call(sub, conv2)                            # 8 x N/BN tiles: the first-generation kernel
+        # rows whose conv window stays inside the first `sub` rows see identical inputs in both launches
+        assert torch.equal(big[:sub - h], small[:sub - h]), (C_, N, k, conv2)
+        assert torch.isfinite(big).all()
