@@ -410,10 +410,35 @@ def test_long_utterance_extends_positional_table(gpu, prec):
     assert e < tol
 
 
-def test_chunked_vocoding_is_bit_identical(gpu):
+@pytest.mark.parametrize("prec", ["fast", "strict"])
+def test_random_ragged_batches_are_batch_invariant(gpu, prec):
+    """Randomised batches (lengths 1-300, random speakers, shuffled order): every utterance's mel / waveform / durations inside any
+    batch are bit-identical to its stand-alone synthesis -- whatever tile, kernel generation or epilogue variant the batch's row
+    counts select (the property that caught the fma-contraction difference between epilogue variants in round 2)."""
+    from oracle import synth_inputs
+    eng = _engine("parity", prec, keep=False)
+    rng = np.random.default_rng(2024)
+    pool_lens = [1, 2, 7, 31, 64, 65, 127, 128, 129, 200, 255, 256, 300]
+    pool = synth_inputs(77, pool_lens, [int(s) for s in rng.integers(0, 2014, len(pool_lens))])
+    solo = []
+    for u in pool:
+        r = eng.synthesize([u])
+        solo.append((r["wav"].copy(), r["mel"].copy(), r["durations"].copy()))
+    for trial in range(4):
+        idx = rng.permutation(len(pool))[: int(rng.integers(2, len(pool) + 1))]
+        out = eng.synthesize([pool[i] for i in idx])
+        cu = out["cu_seqlens"]
+        for b, i in enumerate(idx):
+            assert np.array_equal(out["durations"][cu[b]:cu[b + 1]], solo[i][2]), (trial, int(i))
+            assert np.array_equal(out["mel_list"][b], solo[i][1]), (trial, int(i))
+            assert np.array_equal(out["wav_list"][b], solo[i][0]), (trial, int(i))
+
+
+@pytest.mark.parametrize("prec", ["fast", "strict"])
+def test_chunked_vocoding_is_bit_identical(gpu, prec):
     """Streaming vocoder (EVEngine.vocoder_chunked): chunks with 16 frames of context reproduce whole-utterance vocoding
     bit for bit; with too little context they do not (the receptive field is 14 frames per side)."""
-    eng = _engine("parity", "fast", keep=False)
+    eng = _engine("parity", prec, keep=False)
     rng = np.random.default_rng(17)
     mel = (1.25 * rng.standard_normal((80, 700)) + 0.08).astype(np.float32)
     full = eng.vocoder([mel])["wav"]

@@ -59,6 +59,15 @@ def test_ragged_batch_equals_per_text_oracle(enc):
         assert np.array_equal(solo, got[b]), b                       # batch-invariant, bit for bit
 
 
+def test_longest_text_512_tokens(enc):
+    """max_position_embeddings = 512 tokens (the longest text the reference's tokenizer + BERT accept) against the oracle."""
+    from emotivoice_amd.synthetic import synth_bert_state_dict, synth_token_ids
+    from oracle.bert_oracle import bert_pooled_output
+    ids = synth_token_ids(9, [512])[0]
+    got = enc(input_ids=ids[None])["pooled_output"][0]
+    assert rel_l2(got, bert_pooled_output(synth_bert_state_dict(0), ids).numpy()) < TOL
+
+
 def test_errors(enc):
     from emotivoice_amd.engine import EVError
     with pytest.raises(EVError):
