@@ -13,7 +13,9 @@
 //
 // File map: generic LDS-transposed epilogue (every operand a run-time flag; fp32 / split kernels' fallback) ->
 // specialised straight-line epilogue (template flags, the frame-rate path) -> main conv-GEMM kernel + launch
-// heuristics -> split-precision kernel (token-rate fp32 path) -> fused ResBlock-pair kernels for C = 32 / C = 64.
+// heuristics -> split-precision kernels (fp16 hi/lo, 3 MFMAs per product: first generation 128 x 64 / 4 waves for few-tile
+// token-rate GEMMs, second generation 256 x 128 / 8 waves for the EV_PREC_X3 frame-rate path) -> fused ResBlock-pair kernels
+// for C = 32 / C = 64 -> per-device setup.
 //
 // DT_F16: v_mfma_f32_16x16x32_f16, fp32 accumulate.  DT_F32: v_mfma_f32_16x16x4_f32 (bit-exact
 // fp32 FMA chain) for the duration-critical token-rate path.  Both share the byte geometry:
@@ -685,7 +687,14 @@ static void launch_dt(const ConvGemmParams& p_in, hipStream_t s) {
         // tiles are only used to fill the 256 CUs when there are few tiles.  The fp32 kernel is MFMA-rate bound (1/16 of fp16),
         // weight traffic is irrelevant there, so it only takes the big tile when there are plenty of them.
         static const char* force = getenv("EV_GEMM_TILE");            // "128" / "256": A/B switch for tools/bench_gemm.py
+        static const char* smallm = getenv("EV_GEMM_SMALLM");         // "0" / "1": A/B switch for the latency configuration below
         const long tiles256 = (long)(p.M / 256) * (p.N / 128);
+        // Latency configuration (single utterances: B = 1 is the reference's own call pattern): with a handful of 128-wide tiles most
+        // CUs idle while each tile walks its whole (K-chunk, tap) sequence -- 88 steps = ~70 us for one C = 256 / k = 11 conv of a
+        // 256-phoneme utterance, 169 such dependent launches per forward.  256 x 32 tiles give 4x the blocks with a quarter of the
+        // MFMAs per step.  Same accumulation order per output element, same epilogue: bit-identical results (batch-invariance tests).
+        const bool latency_cfg = sizeof(TIn) == 2 && (smallm ? smallm[0] == '1' : true) && tiles256 < 64;
+        if (latency_cfg && !force) return launch_cfg<TIn, 256, 32, 4, 1>(p, s);
         bool big = tiles256 >= (sizeof(TIn) == 4 ? 2048 : 256);
         if (force) big = force[0] == '2';
         if (big) launch_cfg<TIn, 256, 128, 2, 2>(p, s);
