@@ -232,6 +232,7 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 #define EV_TRACE_ARG , unsigned* trace_out, int trace_flags
 #define EV_TRACE_EPI_PARAMS , unsigned* tr_lds, int& tr_i, int wave
 #define EV_TRACE_EPI_ARGS , tr_lds, tr_i, wave
+#define EV_TRACE_EPI_DUMMY unsigned* tr_lds = nullptr; int tr_i = TRACE_N;      /* kernels without a timeline: stamps disabled */
 #define EV_STAMP()                                                                      \
     {                                                                                   \
         const unsigned t_ = (unsigned)__builtin_readcyclecounter();                     \
@@ -242,6 +243,7 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 #define EV_TRACE_ARG
 #define EV_TRACE_EPI_PARAMS
 #define EV_TRACE_EPI_ARGS
+#define EV_TRACE_EPI_DUMMY
 #define EV_STAMP()
 #endif
 
@@ -254,7 +256,9 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 // pass p+1 are requested before the stores of pass p, (d) row masking is a select, not a branch.
 // RARE_ACT: relu / gelu / tanh (runtime switch).  O16 / O32: exactly one fp16 / one fp32 (after post) output, so that the number
 // of stores per iteration is a compile-time constant and the counted vmcnt waits of the prefetches never drain them.
-enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64, EPI_ADD16 = 128 };
+// LEAN: the operands of a pass are requested at the top of THAT pass instead of one pass ahead (one register set instead of two:
+// the MRF variant of the 128-register phased kernel, whose epilogue is covered by the CU's other block anyway).
+enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64, EPI_ADD16 = 128, EPI_LEAN = 256 };
 __device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
 template <int MT, int NT, int EPI>
@@ -276,27 +280,29 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     for (int pass = 0; pass < NP; ++pass) vld[pass] = vptr[(t0 + pass * 32 + (lane & 31)) >> vshift];
     uint4 r16[2][IT], a16[2][IT][2];
     float4 r32[2][IT][2], a32[2][IT][2];
+    constexpr bool LEAN = (EPI & EPI_LEAN) != 0;
+#define EV_EPI_SET(PASS) (LEAN ? 0 : ((PASS) & 1))
 #define EV_EPI_PREFETCH(PASS)                                                                                              \
     _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                                                    \
         const long t_ = trow + (PASS) * 32 + it * RPI;                                                                     \
         if constexpr (EPI & EPI_RES16)                                                                                     \
-            r16[(PASS) & 1][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.res) + t_ * p.ldres + co); \
+            r16[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.res) + t_ * p.ldres + co); \
         if constexpr (EPI & EPI_RES32) {                                                                                   \
             const float* rp_ = reinterpret_cast<const float*>(p.res) + t_ * p.ldres + co;                                  \
-            r32[(PASS) & 1][it][0] = *reinterpret_cast<const float4*>(rp_);                                                \
-            r32[(PASS) & 1][it][1] = *reinterpret_cast<const float4*>(rp_ + 4);                                            \
+            r32[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const float4*>(rp_);                                          \
+            r32[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const float4*>(rp_ + 4);                                      \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ACC32) {                                                                                   \
             const float* ap_ = p.acc32 + t_ * p.ldacc + co;                                                                \
-            a32[(PASS) & 1][it][0] = *reinterpret_cast<const float4*>(ap_);                                                \
-            a32[(PASS) & 1][it][1] = *reinterpret_cast<const float4*>(ap_ + 4);                                            \
+            a32[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const float4*>(ap_);                                          \
+            a32[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const float4*>(ap_ + 4);                                      \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ADD16) {                                                                                   \
-            a16[(PASS) & 1][it][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_a) + t_ * p.ldadd + co); \
-            a16[(PASS) & 1][it][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_b) + t_ * p.ldadd + co); \
+            a16[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_a) + t_ * p.ldadd + co); \
+            a16[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_b) + t_ * p.ldadd + co); \
         }                                                                                                                  \
     }
-    EV_EPI_PREFETCH(0)
+    if constexpr (!LEAN) { EV_EPI_PREFETCH(0) }
     unsigned vmask[NP];
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) vmask[pass] = (unsigned)__builtin_amdgcn_ballot_w64(vld[pass] != 0);
@@ -329,22 +335,29 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
         __builtin_amdgcn_wave_barrier();
+        if constexpr (LEAN) { EV_EPI_PREFETCH(pass) }
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
             for (int a = 0; a < NT; ++a)
                 *reinterpret_cast<f32x4*>(wave_lds + (bb * 16 + fr) * PITCH + (a * 16 + 4 * fq) * 4) = acc[a][pass * 2 + bb];
         __builtin_amdgcn_wave_barrier();
-        if (pass + 1 < NP) { EV_EPI_PREFETCH(pass + 1) }
+        if constexpr (!LEAN) { if (pass + 1 < NP) { EV_EPI_PREFETCH(pass + 1) } }
         EV_STAMP()
         f32x4 lv[IT][2];          // all of the pass's transposed rows first: one exposed LDS latency per pass, not per iteration
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32);
-            lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32 + 16);
+            for (int it = 0; it < IT; ++it) {
+                lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32);
+                lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32 + 16);
+            }
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
+            if constexpr (LEAN) {         // (row by row: 8 registers instead of 8 * IT)
+                lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32);
+                lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32 + 16);
+            }
             const long off = rowoff + (long)(pass * 32 + it * RPI) * p.ldo;
             const f32x4 v0 = lv[it][0], v1 = lv[it][1];
             f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
@@ -363,23 +376,23 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 for (int j = 0; j < 4; ++j) v[j] = lrelu2(v[j], act_slope2);
             }
             if constexpr (EPI & EPI_RES16) {
-                const half2v* h = reinterpret_cast<const half2v*>(&r16[pass & 1][it]);
+                const half2v* h = reinterpret_cast<const half2v*>(&r16[EV_EPI_SET(pass)][it]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += __builtin_convertvector(h[j], f32x2);
             }
             if constexpr (EPI & EPI_RES32) {
-                const float4 r0 = r32[pass & 1][it][0], r1 = r32[pass & 1][it][1];
+                const float4 r0 = r32[EV_EPI_SET(pass)][it][0], r1 = r32[EV_EPI_SET(pass)][it][1];
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= out_scale2;
             if constexpr (EPI & EPI_ACC32) {
-                const float4 r0 = a32[pass & 1][it][0], r1 = a32[pass & 1][it][1];
+                const float4 r0 = a32[EV_EPI_SET(pass)][it][0], r1 = a32[EV_EPI_SET(pass)][it][1];
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
             }
             if constexpr (EPI & EPI_ADD16) {
-                const half2v* ha = reinterpret_cast<const half2v*>(&a16[pass & 1][it][0]);
-                const half2v* hb = reinterpret_cast<const half2v*>(&a16[pass & 1][it][1]);
+                const half2v* ha = reinterpret_cast<const half2v*>(&a16[EV_EPI_SET(pass)][it][0]);
+                const half2v* hb = reinterpret_cast<const half2v*>(&a16[EV_EPI_SET(pass)][it][1]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += __builtin_convertvector(ha[j], f32x2) + __builtin_convertvector(hb[j], f32x2);
             }
@@ -412,6 +425,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
         }
     }
 #undef EV_EPI_PREFETCH
+#undef EV_EPI_SET
 }
 
 // ---- main kernel.  LDS: 64-byte pitch with an XOR swizzle (16-B part ^= (row >> 1) & 3): conflict-free ds_read_b128 for
@@ -641,19 +655,24 @@ static void launch_epi(const ConvGemmParams& p, hipStream_t s) {
 #endif
 }
 
+// which straight-line epilogue instantiation a fp16 launch asks for (EPI_GENERIC: none)
+static int fp16_epi_variant(const ConvGemmParams& p) {
+    static const bool force_generic = getenv("EV_EPI_GENERIC") != nullptr;     // A/B switch for tools/bench_gemm.py
+    const bool odd_slope = (p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f)) ||
+                           (p.post_lrelu && !(p.post_slope >= 0.f && p.post_slope <= 1.f));     // max(v, s v) form needs s in [0, 1]
+    const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
+    const int omode = (p.out16 && !p.out32) ? EPI_O16 : ((p.out32 && !p.out16 && !p.out32_before_post) ? EPI_O32 : 0);
+    const int base = (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0) | (rare_act ? EPI_RARE_ACT : 0) |
+                     (p.add16_a ? EPI_ADD16 : 0);
+    return p.seq_bias || force_generic || odd_slope ? EPI_GENERIC : (base | omode);
+}
+
 // epilogue variant: the fp16 kernel specialises the combinations the frame-rate path uses (plain / fp16 residual / fp16
 // residual + MRF accumulate / fp32 residual); anything else (per-utterance bias, the fp32 kernel) takes the generic one
 template <typename TIn, int BM, int BN, int WT, int WC>
 static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     if constexpr (sizeof(TIn) == 2) {
-        static const bool force_generic = getenv("EV_EPI_GENERIC") != nullptr;     // A/B switch for tools/bench_gemm.py
-        const bool odd_slope = (p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f)) ||
-                               (p.post_lrelu && !(p.post_slope >= 0.f && p.post_slope <= 1.f));     // max(v, s v) form needs s in [0, 1]
-        const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
-        const int omode = (p.out16 && !p.out32) ? EPI_O16 : ((p.out32 && !p.out16 && !p.out32_before_post) ? EPI_O32 : 0);
-        const int base = (p.res ? (p.res_dtype == DT_F16 ? EPI_RES16 : EPI_RES32) : 0) | (p.acc32 ? EPI_ACC32 : 0) | (rare_act ? EPI_RARE_ACT : 0) |
-                         (p.add16_a ? EPI_ADD16 : 0);
-        int e = p.seq_bias || force_generic || odd_slope ? EPI_GENERIC : (base | omode);
+        int e = fp16_epi_variant(p);
 #define EV_EPI_CASE(E) case (E): return launch_epi<TIn, BM, BN, WT, WC, (E)>(p, s);
         for (int attempt = 0; attempt < 2; ++attempt) {
             switch (e) {
@@ -670,6 +689,235 @@ static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
 #undef EV_EPI_CASE
     }
     launch_epi<TIn, BM, BN, WT, WC, EPI_GENERIC>(p, s);
+}
+
+// =====================================================================================================================
+// Phased conv-GEMM (fp16) for the MFMA-bound shapes (N % 128 == 0, 3 / 7 / 11 taps, enough tiles to fill the chip).
+// Per-wave timelines of conv_gemm_kernel (tools/trace_gemm.py, round 2) show 1 480 cycles of work + 220 of barrier wait per
+// (K-chunk, tap) step against 512 cycles of MFMA: the two 4-wave blocks of a CU are independent, so whether one wave's
+// fragment-read / staging / barrier time is covered by its SIMD partner's MFMA burst is left to chance, and every wave needs
+// the matrix pipe for a third of its time only.  Here the alternation is built in:
+//   * 8 waves per block, two blocks per CU (4 waves per SIMD, <= 128 VGPRs): tile 256 x 128, each wave owns 64 x 64 outputs
+//     (16 accumulator tiles, 16 MFMAs against 8 fragment reads per step);
+//   * waves 0-3 (one per SIMD) and waves 4-7 (their SIMD partners) run the same code one barrier apart: while one group issues
+//     the 16 MFMAs of step s (s_setprio 1), the other one reads the fragments of its next step and issues its share of the
+//     staging traffic; a barrier ends every phase.  On every SIMD exactly one wave of each resident block wants the matrix pipe
+//     at any time;
+//   * staging is LDS-DMA only (global_load_lds_dwordx4, issued through inline asm so that hipcc neither drains vmcnt in front
+//     of the fragment reads nor sees staging registers): the weight tile of step s + 3 (8 KB, one 1-KB piece per wave) into a
+//     ring of four buffers, the activation slab of K-chunk kc + 1 (384 rows x 64 B, three pieces per wave) at the first tap of
+//     chunk kc.  The 64-byte-pitch XOR swizzle of conv_gemm_kernel is applied on the SOURCE side (lane l of a 16-row piece fetches
+//     part (l & 3) ^ ((l >> 3) & 3) of row l >> 2; the DMA writes lane-linear), the fragment reads are unchanged;
+//   * waits are counted, never 0 inside the loop: VMEM returns in order, so "everything this wave issued two phases ago has
+//     landed" is s_waitcnt vmcnt(#pieces issued in this and the previous load phase), a compile-time number because the tap
+//     loop is unrolled (TAPS is a template parameter); the piece is visible to the other waves after the phase's barrier and is
+//     first read two barriers later;
+//   * leaky-relu of the consumer side (pro_lrelu) cannot be applied in flight any more: every wave fixes up its own three slab
+//     pieces in place (ds_read / v_pk_mul + v_pk_max / ds_write) right after the wait that retires them, once per K-chunk;
+//   * a buffer is re-targeted by a DMA only after the barrier that follows the lgkmcnt(0) of its last reader.
+// Same accumulation order per output element as conv_gemm_kernel (K-chunks outer, taps inner, one 32-deep MFMA per step) and the
+// same epilogue functions: results are bit-identical to the 4-wave kernel (tests/test_gpu_ops.py), so the batch-invariance
+// guarantee is untouched by which kernel a launch takes.
+static constexpr int PH_BM = 256, PH_BN = 128, PH_SLABR = 384, PH_NW = 4;
+static constexpr int PH_XBUF = PH_SLABR * 64, PH_WBUF = PH_BN * 64;
+static constexpr size_t PH_LDS = 2 * (size_t)PH_XBUF + PH_NW * (size_t)PH_WBUF;          // 80 KB: two blocks per CU
+
+// 64-bit products are vector instructions on gfx9, so a wave-uniform pointer that involved one lives in VGPRs (and so does everything
+// derived from it); readfirstlane pins it to an SGPR pair (and folds away when the value already is scalar)
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from sbase + voff[lane] to LDS [lds_off + 16 * lane] (M0 carries the LDS address);
+// sbase and lds_off are wave-uniform
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(uniform_ptr(sbase)), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
+
+// accumulate in place.  With the builtin hipcc rotates the 16 accumulator tiles of the unrolled tap loop through fresh registers
+// (dst != srcC in the first steps of every K-chunk): 30 registers over the 128 of four waves per SIMD, and every spill reload inside
+// the loop costs an s_waitcnt vmcnt(0), i.e. the DMA pipeline.  Consecutive uses of one accumulator are 16 MFMAs apart and the
+// fragments were waited for (lgkmcnt(0)) before the phase barrier, so no wait states are owed inside the sequence.
+__device__ __forceinline__ void mfma_inplace(f32x4& c, const half8& a, const half8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int TAPS, int EPI>
+__global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemmParams p) {
+    constexpr int BM = PH_BM, BN = PH_BN, XBUF = PH_XBUF, WBUF = PH_WBUF, NW = PH_NW;
+    constexpr int MT = 4, NT = 4;
+    static_assert(TAPS >= 3 && PH_SLABR >= BM + MAX_SPAN && 8 * 32 * (64 * 4 + 16) <= (int)PH_LDS, "pipeline depth / slab / epilogue scratch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Xs = smem;                 // [2][SLABR][64]
+    char* const Ws = smem + 2 * XBUF;      // [NW][BN][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave & 3, wc = wave >> 2;          // wc is also the phase group: waves w and w + 4 share a SIMD
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int nN = p.N / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (bid / nN) * BM, n0 = (bid % nN) * BN;
+    const int nkc = p.K >> 5;
+    const unsigned a_pitch = (unsigned)p.lda * 2u, w_tap_pitch = (unsigned)p.K * 2u, w_row_pitch = w_tap_pitch * TAPS;
+
+    // DMA sources: uniform 64-bit bases (SGPRs) + one 32-bit lane offset per piece
+    const int prow = lane >> 2, ppart = (lane & 3) ^ ((lane >> 3) & 3);
+    const char* const wbase = uniform_ptr(reinterpret_cast<const char*>(p.W) + (long)n0 * w_row_pitch);
+    const unsigned wvoff = __umul24((unsigned)(wave * 16 + prow), w_row_pitch) + ppart * 16;
+    const char* const xbase = uniform_ptr(reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil) * a_pitch);
+    unsigned xvoff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // rows beyond the conv's real span re-read the last needed row (cache hits) instead of pulling unneeded rows from HBM
+        const int r = (wave + 8 * i) * 16 + prow, rs = min(r, BM + (TAPS - 1) * p.dil - 1);
+        xvoff[i] = __umul24((unsigned)rs, a_pitch) + ppart * 16;         // (24-bit factors: a 32-bit v_mad, not a 64-bit pair)
+    }
+    const unsigned xdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024), wdst = xdst + 2 * XBUF;
+    const bool pro = p.pro_lrelu != 0;
+    const float pro_slope = p.pro_slope;
+
+#define EV_PH_ISSUE_W(KC, TAP, SLOT) glds16(wbase + (unsigned)(TAP) * w_tap_pitch + (unsigned)(KC) * 64u, wvoff, wdst + (unsigned)(SLOT) * WBUF);
+#define EV_PH_ISSUE_X(KC, BUF)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) glds16(xbase + (unsigned)(KC) * 64u, xvoff[i], xdst + (unsigned)(BUF) * XBUF + i * 8192);
+#define EV_PH_FIXUP(BUF)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                \
+        uint4* q_ = reinterpret_cast<uint4*>(Xs + (BUF) * XBUF + (wave + 8 * i) * 1024 + lane * 16);              \
+        *q_ = lrelu_h8(*q_, pro_slope);                                                                            \
+    }
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int woff = swz(wc * 64 + fr, fq);
+
+    // prologue: slab 0 and the weight tiles of steps 0..2, drained; fix-up; everybody meets, then group 1 falls one phase behind
+    EV_PH_ISSUE_X(0, 0)
+    EV_PH_ISSUE_W(0, 0, 0)
+    EV_PH_ISSUE_W(0, 1, 1)
+    EV_PH_ISSUE_W(0, 2, 2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pro) { EV_PH_FIXUP(0) }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wc == 1) __builtin_amdgcn_s_barrier();
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        const bool more = kc + 1 < nkc;
+        const char* const Xb = Xs + (kc & 1) * XBUF;
+        // (opaque copy per K-chunk: otherwise hipcc hoists the fragment addresses of all TAPS taps out of this loop -- 2 VGPRs per
+        // tap, spilled, and a scratch reload inside the loop drains vmcnt, i.e. the whole DMA pipeline)
+        int dil_ = p.dil;
+        asm volatile("" : "+s"(dil_));
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int s = kc * TAPS + tap;
+            // ---------------- load phase: staging requests first, then this step's fragments
+            {
+                const int t3 = (tap + 3 < TAPS) ? tap + 3 : tap + 3 - TAPS;
+                int k3 = (tap + 3 < TAPS) ? kc : kc + 1, t3r = t3;
+                if (k3 >= nkc) { k3 = nkc - 1; t3r = TAPS - 1; }        // past the end: re-request the last tile (keeps the counts static)
+                EV_PH_ISSUE_W(k3, t3r, (s + 3) & 3)
+            }
+            if (tap == 0 && more) { EV_PH_ISSUE_X(kc + 1, (kc + 1) & 1) }
+            // everything issued two load phases ago (and older) has landed: this and the previous phase's pieces may stay in flight
+            if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (tap == 2 && more && pro) {            // (before the fragment reads: its 24 transient registers and theirs never coexist)
+                EV_PH_FIXUP((kc + 1) & 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint4 xf[MT], wf[NT];
+            {
+                const int row0 = wt * 64 + fr + tap * dil_;
+                const char* xp = Xb + row0 * 64 + ((fq ^ ((row0 >> 1) & 3)) << 4);
+                const char* wp = Ws + (s & 3) * WBUF + woff;
+#pragma unroll
+                for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(wp + a * 1024);
+#pragma unroll
+                for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(xp + b * 1024);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- matrix phase
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    mfma_inplace(acc[a][b], *reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf[b]));
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef EV_PH_ISSUE_W
+#undef EV_PH_ISSUE_X
+#undef EV_PH_FIXUP
+    // drain the re-requested tail tiles, let group 1 catch up, then everybody may overwrite the staging buffers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wc == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    {
+        EV_TRACE_EPI_DUMMY
+        gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<64>(), m0 + wt * 64, n0 + wc * 64 EV_TRACE_EPI_ARGS);
+    }
+}
+
+template <int TAPS, int EPI>
+static void launch_phased_epi(const ConvGemmParams& p, hipStream_t s) {
+    const int grid = (p.M / PH_BM) * (p.N / PH_BN);
+    hipLaunchKernelGGL((conv_gemm_phased_kernel<TAPS, EPI>), dim3(grid), dim3(512), PH_LDS, s, p);
+}
+template <int TAPS>
+static bool launch_phased_taps(const ConvGemmParams& p, int e, hipStream_t s) {
+    switch (e) {
+        case EPI_O16: launch_phased_epi<TAPS, EPI_O16>(p, s); return true;
+        case EPI_RES16 | EPI_O16: launch_phased_epi<TAPS, EPI_RES16 | EPI_O16>(p, s); return true;
+        case EPI_RES16 | EPI_ADD16 | EPI_O16: launch_phased_epi<TAPS, EPI_RES16 | EPI_ADD16 | EPI_O16 | EPI_LEAN>(p, s); return true;
+        case EPI_RARE_ACT | EPI_O16: launch_phased_epi<TAPS, EPI_RARE_ACT | EPI_O16>(p, s); return true;
+        default: return false;
+    }
+}
+// true if the launch was taken: fp16, N % 128 == 0, 3 / 7 / 11 taps, one of the four epilogue variants of the frame-rate path
+static bool launch_phased(const ConvGemmParams& p, int e, hipStream_t s) {
+    if (p.N % PH_BN != 0 || p.M % PH_BM != 0 || p.K % 32 != 0 || (p.taps - 1) * p.dil > MAX_SPAN) return false;
+    switch (p.taps) {
+        case 3: return launch_phased_taps<3>(p, e, s);
+        case 7: return launch_phased_taps<7>(p, e, s);
+        case 11: return launch_phased_taps<11>(p, e, s);
+        default: return false;
+    }
+}
+template <int TAPS>
+static hipError_t phased_attr_taps() {
+    hipError_t e = hipSuccess, r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_RES16 | EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_RES16 | EPI_ADD16 | EPI_O16 | EPI_LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_RARE_ACT | EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    return e;
+}
+static hipError_t phased_set_attributes() {
+    hipError_t e = hipSuccess, r;
+    r = phased_attr_taps<3>(); if (r != hipSuccess) e = r;
+    r = phased_attr_taps<7>(); if (r != hipSuccess) e = r;
+    r = phased_attr_taps<11>(); if (r != hipSuccess) e = r;
+    return e;
 }
 
 template <typename TIn>
@@ -695,6 +943,12 @@ static void launch_dt(const ConvGemmParams& p_in, hipStream_t s) {
         // MFMAs per step.  Same accumulation order per output element, same epilogue: bit-identical results (batch-invariance tests).
         const bool latency_cfg = sizeof(TIn) == 2 && (smallm ? smallm[0] == '1' : true) && tiles256 < 64;
         if (latency_cfg && !force) return launch_cfg<TIn, 256, 32, 4, 1>(p, s);
+        if constexpr (sizeof(TIn) == 2) {
+            // phased 8-wave kernel for the shapes that fill the chip with 256 x 128 tiles (bit-identical results, see its header)
+            static const char* ph_env = getenv("EV_GEMM_PHASED");       // "0" / "1": A/B switch
+            const bool ph_on = (ph_env ? ph_env[0] == '1' : true) && !(p.reserved0 & 4);      // reserved0 bit 2: in-process A/B (tools/bench_gemm.py --dbg)
+            if (ph_on && !force && tiles256 >= 256 && launch_phased(p, fp16_epi_variant(p), s)) return;
+        }
         bool big = tiles256 >= (sizeof(TIn) == 4 ? 2048 : 256);
         if (force) big = force[0] == '2';
         if (big) launch_cfg<TIn, 256, 128, 2, 2>(p, s);
@@ -863,7 +1117,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
     gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
 #else
     if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
-    else gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+    else {
+        EV_TRACE_EPI_DUMMY
+        gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC EV_TRACE_EPI_ARGS);
+    }
 #endif
 }
 
@@ -1055,7 +1312,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const ConvGemmPara
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] += accl[a][b] * (1.0f / 2048.0f);
     if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
-    else gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
+    else {
+        EV_TRACE_EPI_DUMMY
+        gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC EV_TRACE_EPI_ARGS);
+    }
 }
 
 template <int BN>
@@ -1747,6 +2007,7 @@ int init_device_kernels(int device) {
     attr((const void*)resblock_pair_c64_kernel<3, 1>, PAIR64_LDS_BYTES);
     attr((const void*)resblock_pair_c64_kernel<3, 2>, PAIR64_LDS_BYTES);
     if (x3_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
+    if (phased_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     g_dev_ready[device] = (e == hipSuccess);
     return e == hipSuccess ? 0 : -1;
 }
@@ -1763,6 +2024,7 @@ void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s) {
 
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {
     // preconditions are checked by the engine (ev_engine.cpp: check_gemm)
+    (void)device_cus();          // per-device large-LDS opt-in for the per-kernel entry points that run without a handle
     if (p.dtype == DT_F16) launch_dt<_Float16>(p, s);
     else if (p.dtype == DT_F32S) launch_split(p, s);
     else launch_dt<float>(p, s);

@@ -67,7 +67,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--dbg", default="0", help="comma list of ConvGemmParams::reserved0 tuning switches to compare (bit 0: s_setprio around the MFMA cluster)")
+    ap.add_argument("--dbg", default="0", help="comma list of ConvGemmParams::reserved0 tuning switches to compare (bit 0: s_setprio around the MFMA cluster of the 4-wave kernel, bit 2 (4): 4-wave kernel instead of the phased 8-wave one)")
     args = ap.parse_args()
     lib = _ffi.lib()
     for name in args.shapes.split(","):
@@ -103,8 +103,10 @@ def main():
         else:
             d.out32 = out.data_ptr()
         d.ldo = N
+        first = None
         for dbg in [int(x) for x in args.dbg.split(",")]:
             d.reserved0 = dbg
+            out.zero_()
             for _ in range(2):
                 lib.ev_op_conv_gemm(C.byref(d), None)
             torch.cuda.synchronize()
@@ -117,8 +119,14 @@ def main():
             ms = e0.elapsed_time(e1) / args.iters
             flops = 2.0 * M * N * K * taps
             byt = M * K * es + M * N * es * (2 if res else 1)
-            print("%-14s dbg=%2d M=%8d K=%4d N=%4d taps=%2d dil=%d  %8.1f us  %7.1f TF/s  %6.2f TB/s" %
-                  (name, dbg, M, K, N, taps, dil, ms * 1e3, flops / ms / 1e9, byt / ms / 1e9), flush=True)
+            # variants selected by the switches must agree bit for bit (same accumulation order, same epilogue code)
+            if first is None:
+                first, same = out.clone(), ""
+            else:
+                nbad = int((out.view(torch.int16 if dtype == 0 else torch.int32) != first.view(torch.int16 if dtype == 0 else torch.int32)).sum())
+                same = "  bits == first" if nbad == 0 else "  %d ELEMENTS DIFFER from first (max |d| %.3g)" % (nbad, float((out.float() - first.float()).abs().max()))
+            print("%-14s dbg=%2d M=%8d K=%4d N=%4d taps=%2d dil=%d  %8.1f us  %7.1f TF/s  %6.2f TB/s%s" %
+                  (name, dbg, M, K, N, taps, dil, ms * 1e3, flops / ms / 1e9, byt / ms / 1e9, same), flush=True)
         del a, w, out, r
 
 

@@ -118,6 +118,15 @@ def report(name, t, shape, us):
     print("   wait[0:%d] " % k + " ".join("%4.0f" % v for v in wait[:, :k].mean(axis=0)))
     if dt.shape[1] > 3 + 2 * steps:      # stamps inside the epilogue: setup | per pass: transpose-in, then one per iteration
         print("   epilogue segments: " + " ".join("%4.0f" % v for v in dt[:, 2 + 2 * steps:].mean(axis=0)))
+    # block phase relations: start / epilogue start / end of wave 0 of every sampled block, in k-cycles from the first start
+    # (do the tiles of one dispatch round run in lockstep, i.e. do all epilogues hit HBM at the same time?)
+    w0 = (ok[:, 0] & 0xFFF) == 0
+    if w0.any() and dt.shape[1] > 2 + 2 * steps:
+        s0 = st[w0]
+        base = s0[:, 0].min()
+        rows = sorted(((int(r[0] - base) & 0xFFFFFFFF) / 1e3, (int(r[2 + 2 * steps] - base) & 0xFFFFFFFF) / 1e3,
+                       (int(r[min(n, TRACE_N) - 1] - base) & 0xFFFFFFFF) / 1e3, int(b)) for r, b in zip(s0, ok[w0][:, 1]))
+        print("   blocks (start, epilogue start, end) k-cycles: " + " | ".join("%d: %.0f %.0f %.0f" % (b, a_, e_, z_) for a_, e_, z_, b in rows[:40]))
     # co-residency: group traced waves by (xcc, cu, simd) from HW_ID
     hw = ok[:, 3]
     print("   hw_id sample: " + " ".join("%08x" % v for v in hw[:4]) + "  xcc " + " ".join(str(v & 15) for v in ok[:4, 4]))
