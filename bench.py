@@ -181,7 +181,7 @@ def roofline_block(eng, work, torch, strict):
         if os.path.exists(tpath) and not strict and work.mode == "am_vocoder" and B == 32:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         name = ("conv_gemm_x3_kernel (split precision: 3 fp16 MFMAs per algorithmic product; every HiFi-GAN Conv1d/ConvTranspose1d)" if strict else
-                "conv_gemm_kernel<f16> (HiFi-GAN Conv1d/ConvTranspose1d: conv_pre, ups, ResBlocks of stages 0-2 except the fused k=3 one)")
+                "conv_gemm_kernel<f16> + conv_gemm_phased_kernel (HiFi-GAN Conv1d/ConvTranspose1d: conv_pre, ups, ResBlocks of stages 0-2 except the fused k=3 one)")
         roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=PEAK_MFMA_F16, unit="TFLOP/s",
                     frac=round(achieved / PEAK_MFMA_F16, 4), traffic=traffic,
                     traffic_note="HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json",

@@ -745,10 +745,22 @@ __device__ __forceinline__ void mfma_inplace(f32x4& c, const half8& a, const hal
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+// Tuning builds only (build.py --variant <tag> EV_PH_ABLATE=<bits>): drop one ingredient of the main loop to see what the phases wait
+// for -- 1: no MFMAs, 2: no fragment reads, 4: no DMA requests, 8: no phase barriers, 16: no epilogue.  Results are garbage by design.
+#ifndef EV_PH_ABLATE
+#define EV_PH_ABLATE 0
+#endif
+// schedule switches (A/B builds): bit 0: staging requests issued inside the matrix phase, bit 1: fragment reads retired after the barrier
+#ifndef EV_PH_SCHED
+#define EV_PH_SCHED 3
+#endif
+
 template <int TAPS, int EPI>
 __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemmParams p) {
-    constexpr int BM = PH_BM, BN = PH_BN, XBUF = PH_XBUF, WBUF = PH_WBUF, NW = PH_NW;
+    constexpr int BM = PH_BM, BN = PH_BN, XBUF = PH_XBUF, WBUF = PH_WBUF;
     constexpr int MT = 4, NT = 4;
+    constexpr bool DMA_IN_MMA = (EV_PH_SCHED & 1) != 0, LGKM_AFTER = (EV_PH_SCHED & 2) != 0;
+    static_assert(!LGKM_AFTER || DMA_IN_MMA, "a buffer may be re-targeted one phase after its last read only if that read was retired before the barrier");
     static_assert(TAPS >= 3 && PH_SLABR >= BM + MAX_SPAN && 8 * 32 * (64 * 4 + 16) <= (int)PH_LDS, "pipeline depth / slab / epilogue scratch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Xs = smem;                 // [2][SLABR][64]
@@ -785,9 +797,9 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
     const bool pro = p.pro_lrelu != 0;
     const float pro_slope = p.pro_slope;
 
-#define EV_PH_ISSUE_W(KC, TAP, SLOT) glds16(wbase + (unsigned)(TAP) * w_tap_pitch + (unsigned)(KC) * 64u, wvoff, wdst + (unsigned)(SLOT) * WBUF);
+#define EV_PH_ISSUE_W(KC, TAP, SLOT) if (!(EV_PH_ABLATE & 4)) glds16(wbase + (unsigned)(TAP) * w_tap_pitch + (unsigned)(KC) * 64u, wvoff, wdst + (unsigned)(SLOT) * WBUF);
 #define EV_PH_ISSUE_X(KC, BUF)                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) glds16(xbase + (unsigned)(KC) * 64u, xvoff[i], xdst + (unsigned)(BUF) * XBUF + i * 8192);
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) if (!(EV_PH_ABLATE & 4)) glds16(xbase + (unsigned)(KC) * 64u, xvoff[i], xdst + (unsigned)(BUF) * XBUF + i * 8192);
 #define EV_PH_FIXUP(BUF)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                \
         uint4* q_ = reinterpret_cast<uint4*>(Xs + (BUF) * XBUF + (wave + 8 * i) * 1024 + lane * 16);              \
@@ -823,45 +835,73 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int s = kc * TAPS + tap;
-            // ---------------- load phase: staging requests first, then this step's fragments
-            {
-                const int t3 = (tap + 3 < TAPS) ? tap + 3 : tap + 3 - TAPS;
-                int k3 = (tap + 3 < TAPS) ? kc : kc + 1, t3r = t3;
-                if (k3 >= nkc) { k3 = nkc - 1; t3r = TAPS - 1; }        // past the end: re-request the last tile (keeps the counts static)
-                EV_PH_ISSUE_W(k3, t3r, (s + 3) & 3)
+            // ---------------- load phase: this step's fragments; the staging requests of two steps ago are retired
+            int k3 = (tap + 3 < TAPS) ? kc : kc + 1, t3 = (tap + 3 < TAPS) ? tap + 3 : tap + 3 - TAPS;
+            if (k3 >= nkc) { k3 = nkc - 1; t3 = TAPS - 1; }            // past the end: re-request the last tile (keeps the counts static)
+            if constexpr (!DMA_IN_MMA) {
+                EV_PH_ISSUE_W(k3, t3, (s + 3) & 3)
+                if (tap == 0 && more) { EV_PH_ISSUE_X(kc + 1, (kc + 1) & 1) }
             }
-            if (tap == 0 && more) { EV_PH_ISSUE_X(kc + 1, (kc + 1) & 1) }
-            // everything issued two load phases ago (and older) has landed: this and the previous phase's pieces may stay in flight
-            if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            if (tap == 2 && more && pro) {            // (before the fragment reads: its 24 transient registers and theirs never coexist)
-                EV_PH_FIXUP((kc + 1) & 1)
-                __builtin_amdgcn_sched_barrier(0);
+            // VMEM returns in order: "the pieces this wave requested for step s + 1 (and the slab, at tap 2) have landed" = at most the
+            // requests issued after them are outstanding
+#define EV_PH_WAIT_VM                                                                                                   \
+            if constexpr (DMA_IN_MMA) { if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); } \
+            else { if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+            if (tap == 2) {                       // (fix-up before the fragment reads: its 24 transient registers and theirs never coexist)
+                EV_PH_WAIT_VM
+                if (more && pro) {
+                    EV_PH_FIXUP((kc + 1) & 1)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             uint4 xf[MT], wf[NT];
             {
                 const int row0 = wt * 64 + fr + tap * dil_;
                 const char* xp = Xb + row0 * 64 + ((fq ^ ((row0 >> 1) & 3)) << 4);
                 const char* wp = Ws + (s & 3) * WBUF + woff;
+                if constexpr ((EV_PH_ABLATE & 2) == 0) {
 #pragma unroll
-                for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(wp + a * 1024);
+                    for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(wp + a * 1024);
 #pragma unroll
-                for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(xp + b * 1024);
+                    for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(xp + b * 1024);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < NT; ++a) { wf[a] = make_uint4(s, lane, a, tap); asm volatile("" : "+v"(wf[a].x), "+v"(wf[a].y), "+v"(wf[a].z), "+v"(wf[a].w)); }
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) { xf[b] = make_uint4(s, lane, b, tap); asm volatile("" : "+v"(xf[b].x), "+v"(xf[b].y), "+v"(xf[b].z), "+v"(xf[b].w)); }
+                    asm volatile("" :: "v"(xp), "v"(wp));
+                }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tap != 2) { EV_PH_WAIT_VM }
+#undef EV_PH_WAIT_VM
+            if constexpr (!LGKM_AFTER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            // (LGKM_AFTER: no explicit wait here -- hipcc's own counted lgkmcnt in front of each MFMA's first use retires the reads)
             __builtin_amdgcn_sched_barrier(0);
-            // ---------------- matrix phase
+            // ---------------- matrix phase (+ the staging requests, in the shadow of the MFMAs)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int a = 0; a < NT; ++a)
+            for (int a = 0; a < NT; ++a) {
 #pragma unroll
-                for (int b = 0; b < MT; ++b)
-                    mfma_inplace(acc[a][b], *reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf[b]));
+                for (int b = 0; b < MT; ++b) {
+                    if constexpr ((EV_PH_ABLATE & 1) == 0) mfma_inplace(acc[a][b], *reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf[b]));
+                    else asm volatile("" : "+v"(acc[a][b]) : "v"(*reinterpret_cast<half8*>(&wf[a])), "v"(*reinterpret_cast<half8*>(&xf[b])));
+                    if constexpr (DMA_IN_MMA) {
+                        constexpr int XI[3] = {5, 8, 11};
+                        if (a * MT + b == 2) { EV_PH_ISSUE_W(k3, t3, (s + 3) & 3) }
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            if (a * MT + b == XI[i] && tap == 0 && more) {
+                                if (!(EV_PH_ABLATE & 4)) glds16(xbase + (unsigned)(kc + 1) * 64u, xvoff[i], xdst + (unsigned)((kc + 1) & 1) * XBUF + i * 8192);
+                            }
+                    }
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -872,9 +912,14 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wc == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
-    {
+    if constexpr ((EV_PH_ABLATE & 16) == 0) {
         EV_TRACE_EPI_DUMMY
         gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<64>(), m0 + wt * 64, n0 + wc * 64 EV_TRACE_EPI_ARGS);
+    } else {
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) asm volatile("" :: "v"(acc[a][b]));
     }
 }
 

@@ -39,9 +39,14 @@ def forwards(rows):
     return out
 
 
+def _is_f16_gemm(name):
+    return "conv_gemm_kernelIDF16" in name or "conv_gemm_phased_kernel" in name
+
+
 FAMILIES = {
-    "conv_gemm_f16_vocoder": lambda f: [r for r in f if "conv_gemm_kernelIDF16" in r["Kernel_Name"]][N_DEC:],
-    "conv_gemm_f16_decoder": lambda f: [r for r in f if "conv_gemm_kernelIDF16" in r["Kernel_Name"]][:N_DEC],
+    # (the fp16 family = the 4-wave kernel + the phased 8-wave kernel that takes its MFMA-bound shapes)
+    "conv_gemm_f16_vocoder": lambda f: [r for r in f if _is_f16_gemm(r["Kernel_Name"])][N_DEC:],
+    "conv_gemm_f16_decoder": lambda f: [r for r in f if _is_f16_gemm(r["Kernel_Name"])][:N_DEC],
     "resblock_pair_c32_c64": lambda f: [r for r in f if "resblock_pair_c" in r["Kernel_Name"]],
     "attention_mfma_f16": lambda f: [r for r in f if "attention_mfma_kernel" in r["Kernel_Name"]],
     "conv_gemm_split_token_rate": lambda f: [r for r in f if "conv_gemm_split_kernel" in r["Kernel_Name"] or "conv_gemm_x3_kernel" in r["Kernel_Name"]],
