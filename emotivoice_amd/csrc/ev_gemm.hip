@@ -755,24 +755,28 @@ __device__ __forceinline__ void mfma_inplace(f32x4& c, const half8& a, const hal
 #define EV_PH_SCHED 3
 #endif
 
-template <int TAPS, int EPI>
-__global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemmParams p) {
-    constexpr int BM = PH_BM, BN = PH_BN, XBUF = PH_XBUF, WBUF = PH_WBUF;
-    constexpr int MT = 4, NT = 4;
+template <int TAPS, int BN, int EPI>
+__device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, int bid, const int nblk) {
+    // BN = 128: one tap per step, each wave 64 x 64 outputs.  BN = 64 (the C = 64 stage): each wave 64 x 32 outputs and a step covers TWO
+    // taps, so that a matrix phase is 16 MFMAs in both cases and the weight tile of a step is 8 KB = one DMA piece per wave in both
+    // (BN = 64: [2 taps][64 rows][64 B]; the second tap of the last, odd step is a harmless re-request of the last tap).
+    constexpr int BM = PH_BM, XBUF = PH_XBUF, WBUF = PH_WBUF;
+    constexpr int TPS = (BN == 64) ? 2 : 1;              // taps per step
+    constexpr int U = (TAPS + TPS - 1) / TPS;            // steps per K-chunk
+    constexpr int TC = BN / 2, MT = 4, NT = TC / 16;
     constexpr bool DMA_IN_MMA = (EV_PH_SCHED & 1) != 0, LGKM_AFTER = (EV_PH_SCHED & 2) != 0;
+    static_assert(BN == 128 || BN == 64, "tile width");
     static_assert(!LGKM_AFTER || DMA_IN_MMA, "a buffer may be re-targeted one phase after its last read only if that read was retired before the barrier");
-    static_assert(TAPS >= 3 && PH_SLABR >= BM + MAX_SPAN && 8 * 32 * (64 * 4 + 16) <= (int)PH_LDS, "pipeline depth / slab / epilogue scratch");
+    static_assert(U >= 3 && PH_SLABR >= BM + MAX_SPAN && 8 * 32 * (TC * 4 + 16) <= (int)PH_LDS, "pipeline depth / slab / epilogue scratch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Xs = smem;                 // [2][SLABR][64]
-    char* const Ws = smem + 2 * XBUF;      // [NW][BN][64]
+    char* const Ws = smem + 2 * XBUF;      // [NW][8 KB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wt = wave & 3, wc = wave >> 2;          // wc is also the phase group: waves w and w + 4 share a SIMD
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     const int nN = p.N / BN;
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
@@ -781,10 +785,12 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
     const int nkc = p.K >> 5;
     const unsigned a_pitch = (unsigned)p.lda * 2u, w_tap_pitch = (unsigned)p.K * 2u, w_row_pitch = w_tap_pitch * TAPS;
 
-    // DMA sources: uniform 64-bit bases (SGPRs) + one 32-bit lane offset per piece
+    // DMA sources: uniform 64-bit bases (SGPRs) + one 32-bit lane offset per piece.  Weight piece of wave w: rows 16 w .. 16 w + 15 of the
+    // tile (BN = 128) / rows 16 (w & 3) .. of tap 2 u + (w >> 2) (BN = 64)
     const int prow = lane >> 2, ppart = (lane & 3) ^ ((lane >> 3) & 3);
+    const int wprow = (BN == 128 ? wave : (wave & 3)) * 16 + prow, wtapj = (BN == 128) ? 0 : (wave >> 2);
     const char* const wbase = uniform_ptr(reinterpret_cast<const char*>(p.W) + (long)n0 * w_row_pitch);
-    const unsigned wvoff = __umul24((unsigned)(wave * 16 + prow), w_row_pitch) + ppart * 16;
+    const unsigned wvoff = __umul24((unsigned)wprow, w_row_pitch) + ppart * 16;
     const char* const xbase = uniform_ptr(reinterpret_cast<const char*>(p.A) + ((long)m0 - (long)p.center * p.dil) * a_pitch);
     unsigned xvoff[3];
 #pragma unroll
@@ -797,9 +803,13 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
     const bool pro = p.pro_lrelu != 0;
     const float pro_slope = p.pro_slope;
 
-#define EV_PH_ISSUE_W(KC, TAP, SLOT) if (!(EV_PH_ABLATE & 4)) glds16(wbase + (unsigned)(TAP) * w_tap_pitch + (unsigned)(KC) * 64u, wvoff, wdst + (unsigned)(SLOT) * WBUF);
-#define EV_PH_ISSUE_X(KC, BUF)                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) if (!(EV_PH_ABLATE & 4)) glds16(xbase + (unsigned)(KC) * 64u, xvoff[i], xdst + (unsigned)(BUF) * XBUF + i * 8192);
+    // weight tile of step US of K-chunk KC -> ring slot SLOT
+#define EV_PH_ISSUE_W(KC, US, SLOT)                                                                                \
+    if (!(EV_PH_ABLATE & 4)) {                                                                                     \
+        const int tp_ = min((US) * TPS + wtapj, TAPS - 1);                                                         \
+        glds16(wbase + (unsigned)tp_ * w_tap_pitch + (unsigned)(KC) * 64u, wvoff, wdst + (unsigned)(SLOT) * WBUF);  \
+    }
+#define EV_PH_ISSUE_X1(KC, BUF, I) if (!(EV_PH_ABLATE & 4)) glds16(xbase + (unsigned)(KC) * 64u, xvoff[I], xdst + (unsigned)(BUF) * XBUF + (I) * 8192);
 #define EV_PH_FIXUP(BUF)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                \
         uint4* q_ = reinterpret_cast<uint4*>(Xs + (BUF) * XBUF + (wave + 8 * i) * 1024 + lane * 16);              \
@@ -812,10 +822,12 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    const int woff = swz(wc * 64 + fr, fq);
+    const int woff = swz(wc * TC + fr, fq);
 
     // prologue: slab 0 and the weight tiles of steps 0..2, drained; fix-up; everybody meets, then group 1 falls one phase behind
-    EV_PH_ISSUE_X(0, 0)
+    EV_PH_ISSUE_X1(0, 0, 0)
+    EV_PH_ISSUE_X1(0, 0, 1)
+    EV_PH_ISSUE_X1(0, 0, 2)
     EV_PH_ISSUE_W(0, 0, 0)
     EV_PH_ISSUE_W(0, 1, 1)
     EV_PH_ISSUE_W(0, 2, 2)
@@ -833,21 +845,22 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
         int dil_ = p.dil;
         asm volatile("" : "+s"(dil_));
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int s = kc * TAPS + tap;
+        for (int u = 0; u < U; ++u) {
+            const int s = kc * U + u;
+            const int ntap = (u * TPS + TPS <= TAPS) ? TPS : 1;       // taps of this step (static after unrolling)
             // ---------------- load phase: this step's fragments; the staging requests of two steps ago are retired
-            int k3 = (tap + 3 < TAPS) ? kc : kc + 1, t3 = (tap + 3 < TAPS) ? tap + 3 : tap + 3 - TAPS;
-            if (k3 >= nkc) { k3 = nkc - 1; t3 = TAPS - 1; }            // past the end: re-request the last tile (keeps the counts static)
+            int k3 = (u + 3 < U) ? kc : kc + 1, u3 = (u + 3 < U) ? u + 3 : u + 3 - U;
+            if (k3 >= nkc) { k3 = nkc - 1; u3 = U - 1; }               // past the end: re-request the last tile (keeps the counts static)
             if constexpr (!DMA_IN_MMA) {
-                EV_PH_ISSUE_W(k3, t3, (s + 3) & 3)
-                if (tap == 0 && more) { EV_PH_ISSUE_X(kc + 1, (kc + 1) & 1) }
+                EV_PH_ISSUE_W(k3, u3, (s + 3) & 3)
+                if (u == 0 && more) { EV_PH_ISSUE_X1(kc + 1, (kc + 1) & 1, 0) EV_PH_ISSUE_X1(kc + 1, (kc + 1) & 1, 1) EV_PH_ISSUE_X1(kc + 1, (kc + 1) & 1, 2) }
             }
-            // VMEM returns in order: "the pieces this wave requested for step s + 1 (and the slab, at tap 2) have landed" = at most the
+            // VMEM returns in order: "the pieces this wave requested for step s + 1 (and the slab, at step 2) have landed" = at most the
             // requests issued after them are outstanding
 #define EV_PH_WAIT_VM                                                                                                   \
-            if constexpr (DMA_IN_MMA) { if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); } \
-            else { if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-            if (tap == 2) {                       // (fix-up before the fragment reads: its 24 transient registers and theirs never coexist)
+            if constexpr (DMA_IN_MMA) { if (u == 1 && more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); } \
+            else { if (u <= 1 && more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+            if (u == 2) {                         // (fix-up before the fragment reads: its 24 transient registers and theirs never coexist)
                 EV_PH_WAIT_VM
                 if (more && pro) {
                     EV_PH_FIXUP((kc + 1) & 1)
@@ -855,25 +868,27 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            uint4 xf[MT], wf[NT];
-            {
-                const int row0 = wt * 64 + fr + tap * dil_;
+            uint4 xf[TPS][MT], wf[TPS][NT];
+#pragma unroll
+            for (int j = 0; j < TPS; ++j) {
+                if (j >= ntap) continue;
+                const int row0 = wt * 64 + fr + (u * TPS + j) * dil_;
                 const char* xp = Xb + row0 * 64 + ((fq ^ ((row0 >> 1) & 3)) << 4);
-                const char* wp = Ws + (s & 3) * WBUF + woff;
+                const char* wp = Ws + (s & 3) * WBUF + j * 4096 + woff;
                 if constexpr ((EV_PH_ABLATE & 2) == 0) {
 #pragma unroll
-                    for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(wp + a * 1024);
+                    for (int a = 0; a < NT; ++a) wf[j][a] = *reinterpret_cast<const uint4*>(wp + a * 1024);
 #pragma unroll
-                    for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(xp + b * 1024);
+                    for (int b = 0; b < MT; ++b) xf[j][b] = *reinterpret_cast<const uint4*>(xp + b * 1024);
                 } else {
 #pragma unroll
-                    for (int a = 0; a < NT; ++a) { wf[a] = make_uint4(s, lane, a, tap); asm volatile("" : "+v"(wf[a].x), "+v"(wf[a].y), "+v"(wf[a].z), "+v"(wf[a].w)); }
+                    for (int a = 0; a < NT; ++a) { wf[j][a] = make_uint4(s, lane, a, u); asm volatile("" : "+v"(wf[j][a].x), "+v"(wf[j][a].y), "+v"(wf[j][a].z), "+v"(wf[j][a].w)); }
 #pragma unroll
-                    for (int b = 0; b < MT; ++b) { xf[b] = make_uint4(s, lane, b, tap); asm volatile("" : "+v"(xf[b].x), "+v"(xf[b].y), "+v"(xf[b].z), "+v"(xf[b].w)); }
+                    for (int b = 0; b < MT; ++b) { xf[j][b] = make_uint4(s, lane, b, u); asm volatile("" : "+v"(xf[j][b].x), "+v"(xf[j][b].y), "+v"(xf[j][b].z), "+v"(xf[j][b].w)); }
                     asm volatile("" :: "v"(xp), "v"(wp));
                 }
             }
-            if (tap != 2) { EV_PH_WAIT_VM }
+            if (u != 2) { EV_PH_WAIT_VM }
 #undef EV_PH_WAIT_VM
             if constexpr (!LGKM_AFTER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -883,19 +898,23 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
             // ---------------- matrix phase (+ the staging requests, in the shadow of the MFMAs)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int a = 0; a < NT; ++a) {
+            for (int j = 0; j < TPS; ++j) {
+                if (j >= ntap) continue;
 #pragma unroll
-                for (int b = 0; b < MT; ++b) {
-                    if constexpr ((EV_PH_ABLATE & 1) == 0) mfma_inplace(acc[a][b], *reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf[b]));
-                    else asm volatile("" : "+v"(acc[a][b]) : "v"(*reinterpret_cast<half8*>(&wf[a])), "v"(*reinterpret_cast<half8*>(&xf[b])));
-                    if constexpr (DMA_IN_MMA) {
-                        constexpr int XI[3] = {5, 8, 11};
-                        if (a * MT + b == 2) { EV_PH_ISSUE_W(k3, t3, (s + 3) & 3) }
+                for (int a = 0; a < NT; ++a) {
 #pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            if (a * MT + b == XI[i] && tap == 0 && more) {
-                                if (!(EV_PH_ABLATE & 4)) glds16(xbase + (unsigned)(kc + 1) * 64u, xvoff[i], xdst + (unsigned)((kc + 1) & 1) * XBUF + i * 8192);
+                    for (int b = 0; b < MT; ++b) {
+                        if constexpr ((EV_PH_ABLATE & 1) == 0) mfma_inplace(acc[a][b], *reinterpret_cast<half8*>(&wf[j][a]), *reinterpret_cast<half8*>(&xf[j][b]));
+                        else asm volatile("" : "+v"(acc[a][b]) : "v"(*reinterpret_cast<half8*>(&wf[j][a])), "v"(*reinterpret_cast<half8*>(&xf[j][b])));
+                        if constexpr (DMA_IN_MMA) {
+                            const int idx = (j * NT + a) * MT + b;            // position in the phase's MFMA sequence (8 or 16 long)
+                            if (idx == 2) { EV_PH_ISSUE_W(k3, u3, (s + 3) & 3) }
+                            if (u == 0 && more) {
+                                if (idx == 4) { EV_PH_ISSUE_X1(kc + 1, (kc + 1) & 1, 0) }
+                                if (idx == 5) { EV_PH_ISSUE_X1(kc + 1, (kc + 1) & 1, 1) }
+                                if (idx == 6) { EV_PH_ISSUE_X1(kc + 1, (kc + 1) & 1, 2) }
                             }
+                        }
                     }
                 }
             }
@@ -906,7 +925,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
         }
     }
 #undef EV_PH_ISSUE_W
-#undef EV_PH_ISSUE_X
+#undef EV_PH_ISSUE_X1
 #undef EV_PH_FIXUP
     // drain the re-requested tail tiles, let group 1 catch up, then everybody may overwrite the staging buffers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -914,7 +933,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
     __builtin_amdgcn_s_barrier();
     if constexpr ((EV_PH_ABLATE & 16) == 0) {
         EV_TRACE_EPI_DUMMY
-        gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<64>(), m0 + wt * 64, n0 + wc * 64 EV_TRACE_EPI_ARGS);
+        gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC EV_TRACE_EPI_ARGS);
     } else {
 #pragma unroll
         for (int a = 0; a < NT; ++a)
@@ -923,45 +942,65 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemm
     }
 }
 
-template <int TAPS, int EPI>
-static void launch_phased_epi(const ConvGemmParams& p, hipStream_t s) {
-    const int grid = (p.M / PH_BM) * (p.N / PH_BN);
-    hipLaunchKernelGGL((conv_gemm_phased_kernel<TAPS, EPI>), dim3(grid), dim3(512), PH_LDS, s, p);
+template <int TAPS, int BN, int EPI>
+__global__ __launch_bounds__(512, 4) void conv_gemm_phased_kernel(const ConvGemmParams p) {
+    conv_gemm_phased_body<TAPS, BN, EPI>(p, blockIdx.x, gridDim.x);
 }
-template <int TAPS>
+
+template <int TAPS, int BN, int EPI>
+static void launch_phased_epi(const ConvGemmParams& p, hipStream_t s) {
+    const int grid = (p.M / PH_BM) * (p.N / BN);
+    hipLaunchKernelGGL((conv_gemm_phased_kernel<TAPS, BN, EPI>), dim3(grid), dim3(512), PH_LDS, s, p);
+}
+template <int TAPS, int BN>
 static bool launch_phased_taps(const ConvGemmParams& p, int e, hipStream_t s) {
     switch (e) {
-        case EPI_O16: launch_phased_epi<TAPS, EPI_O16>(p, s); return true;
-        case EPI_RES16 | EPI_O16: launch_phased_epi<TAPS, EPI_RES16 | EPI_O16>(p, s); return true;
-        case EPI_RES16 | EPI_ADD16 | EPI_O16: launch_phased_epi<TAPS, EPI_RES16 | EPI_ADD16 | EPI_O16 | EPI_LEAN>(p, s); return true;
-        case EPI_RARE_ACT | EPI_O16: launch_phased_epi<TAPS, EPI_RARE_ACT | EPI_O16>(p, s); return true;
+        case EPI_O16: launch_phased_epi<TAPS, BN, EPI_O16>(p, s); return true;
+        case EPI_RES16 | EPI_O16: launch_phased_epi<TAPS, BN, EPI_RES16 | EPI_O16>(p, s); return true;
+        case EPI_RES16 | EPI_ADD16 | EPI_O16: launch_phased_epi<TAPS, BN, EPI_RES16 | EPI_ADD16 | EPI_O16 | EPI_LEAN>(p, s); return true;
+        case EPI_RARE_ACT | EPI_O16:
+            if constexpr (BN == 128) { launch_phased_epi<TAPS, BN, EPI_RARE_ACT | EPI_O16>(p, s); return true; }
+            return false;
         default: return false;
     }
 }
-// true if the launch was taken: fp16, N % 128 == 0, 3 / 7 / 11 taps, one of the four epilogue variants of the frame-rate path
+// true if the launch was taken: fp16; N % 128 == 0 with 3 / 7 / 11 taps, or N % 64 == 0 with 11 taps; one of the four epilogue
+// variants of the frame-rate path
 static bool launch_phased(const ConvGemmParams& p, int e, hipStream_t s) {
-    if (p.N % PH_BN != 0 || p.M % PH_BM != 0 || p.K % 32 != 0 || (p.taps - 1) * p.dil > MAX_SPAN) return false;
-    switch (p.taps) {
-        case 3: return launch_phased_taps<3>(p, e, s);
-        case 7: return launch_phased_taps<7>(p, e, s);
-        case 11: return launch_phased_taps<11>(p, e, s);
-        default: return false;
+    if (p.M % PH_BM != 0 || p.K % 32 != 0 || (p.taps - 1) * p.dil > MAX_SPAN) return false;
+    if (p.N % 128 == 0) {
+        switch (p.taps) {
+            case 3: return launch_phased_taps<3, 128>(p, e, s);
+            case 7: return launch_phased_taps<7, 128>(p, e, s);
+            case 11: return launch_phased_taps<11, 128>(p, e, s);
+            default: return false;
+        }
     }
+    if (p.N % 64 == 0) {
+        // measured (tools/bench_gemm.py --dbg 4,0): k = 11 +0...10 %, k = 7 -8 % (4.4 TB/s: HBM-bound, the 4-wave kernel's 3 blocks per CU hide
+        // the latency better) -- only the 11-tap layers take it
+        if (p.taps == 11) return launch_phased_taps<11, 64>(p, e, s);
+        return false;
+    }
+    return false;
 }
-template <int TAPS>
+template <int TAPS, int BN>
 static hipError_t phased_attr_taps() {
     hipError_t e = hipSuccess, r;
-    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
-    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_RES16 | EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
-    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_RES16 | EPI_ADD16 | EPI_O16 | EPI_LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
-    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, EPI_RARE_ACT | EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, BN, EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, BN, EPI_RES16 | EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, BN, EPI_RES16 | EPI_ADD16 | EPI_O16 | EPI_LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    if constexpr (BN == 128) {
+        r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, BN, EPI_RARE_ACT | EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    }
     return e;
 }
 static hipError_t phased_set_attributes() {
     hipError_t e = hipSuccess, r;
-    r = phased_attr_taps<3>(); if (r != hipSuccess) e = r;
-    r = phased_attr_taps<7>(); if (r != hipSuccess) e = r;
-    r = phased_attr_taps<11>(); if (r != hipSuccess) e = r;
+    r = phased_attr_taps<3, 128>(); if (r != hipSuccess) e = r;
+    r = phased_attr_taps<7, 128>(); if (r != hipSuccess) e = r;
+    r = phased_attr_taps<11, 128>(); if (r != hipSuccess) e = r;
+    r = phased_attr_taps<11, 64>(); if (r != hipSuccess) e = r;
     return e;
 }
 
@@ -998,8 +1037,14 @@ static void launch_dt(const ConvGemmParams& p_in, hipStream_t s) {
         if (force) big = force[0] == '2';
         if (big) launch_cfg<TIn, 256, 128, 2, 2>(p, s);
         else launch_cfg<TIn, 128, 128, 2, 2>(p, s);
-    } else if (p.N % 64 == 0) launch_cfg<TIn, 256, 64, 4, 1>(p, s);
-    else launch_cfg<TIn, 256, 32, 4, 1>(p, s);
+    } else if (p.N % 64 == 0) {
+        if constexpr (sizeof(TIn) == 2) {          // C = 64 stage, 7 / 11 taps: phased kernel with two taps per step
+            static const char* ph_env = getenv("EV_GEMM_PHASED");
+            const bool ph_on = (ph_env ? ph_env[0] == '1' : true) && !(p.reserved0 & 4);
+            if (ph_on && (long)(p.M / 256) * (p.N / 64) >= 512 && launch_phased(p, fp16_epi_variant(p), s)) return;
+        }
+        launch_cfg<TIn, 256, 64, 4, 1>(p, s);
+    } else launch_cfg<TIn, 256, 32, 4, 1>(p, s);
 }
 
 // =====================================================================================================================

@@ -36,7 +36,7 @@ def _padded(rows, cols, dtype, fill=None):
 
 def _run_conv(lib, x_view, w_torch, bias, *, dtype, taps, dil, center, row_valid=None, valid_shift=0, act=0, act_slope=0.0,
               pro_slope=None, res=None, scale=1.0, acc32=None, post_slope=None, seq_bias=None, row_seq=None,
-              want16=True, want32=True, before_post=False, add16=None):
+              want16=True, want32=True, before_post=False, add16=None, dbg=0):
     from emotivoice_amd import _ffi
     M, K = x_view.shape
     N = w_torch.shape[0]
@@ -70,6 +70,7 @@ def _run_conv(lib, x_view, w_torch, bias, *, dtype, taps, dil, center, row_valid
     d.out32 = out32.data_ptr() if want32 else None
     d.ldo = N
     d.out32_before_post = 1 if before_post else 0
+    d.reserved0 = dbg            # tuning / A-B switches of the launcher (bit 2: 4-wave kernel instead of the phased 8-wave one)
     torch.cuda.synchronize()
     rc = lib.ev_op_conv_gemm(C.byref(d), None)
     assert rc == 0
@@ -217,6 +218,72 @@ def test_conv_gemm_mrf16_and_static_outputs(lib, C_, taps, outs, M):
                        act=3, act_slope=0.1, want16=True, want32=False)
     assert _rel(o16.float().cpu(), ref) < 6e-4
     assert float(o16[~vrow].float().abs().max()) == 0.0
+
+
+PHASED_CASES = [
+    # name, M, K, N, taps, dil, epilogue class
+    ("c128_k11_d5_pro", 65536, 128, 128, 11, 5, "pro"),
+    ("c128_k7_d1_res", 65536, 128, 128, 7, 1, "res"),
+    ("c128_k3_d1_pro", 65536, 128, 128, 3, 1, "pro"),
+    ("c128_k11_d1_mrf", 65536, 128, 128, 11, 1, "mrf"),
+    ("c256_k7_d3_res_masked", 33024, 256, 256, 7, 3, "res_masked"),
+    ("c64_k11_d5_pro", 131072, 64, 64, 11, 5, "pro"),
+    ("c64_k11_d1_mrf", 131072, 64, 64, 11, 1, "mrf"),
+    ("ffn1_gelu", 8192, 384, 1536, 3, 1, "gelu"),
+    ("ffn2_res", 22016, 1536, 384, 3, 1, "res"),
+    ("conv_pre_k7", 33024, 96, 512, 7, 1, "plain"),
+]
+
+
+@pytest.mark.parametrize("case", PHASED_CASES, ids=[c[0] for c in PHASED_CASES])
+def test_phased_kernel_matches_4_wave_kernel_bitwise(lib, case):
+    """Large launches of the frame-rate path take conv_gemm_phased_kernel (8 waves, LDS-DMA staging, alternating matrix / load
+    phases); it must reproduce the 4-wave kernel bit for bit -- which kernel runs depends on the batch's row count, and the engine
+    promises batch-invariant results -- and, on its own, the fp32 torch conv (models/hifigan/models.py:50-57,116-128)."""
+    name, M, K, N, taps, dil, cls = case
+    torch.manual_seed(len(name) * 7 + taps)
+    full, x = _padded(M, K, torch.float16)
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    w = (torch.randn(N, K, taps, device="cuda") / math.sqrt(K * taps)).half()
+    bias = torch.randn(N, device="cuda")
+    center = (taps - 1) // 2
+    kw = dict(dtype=0, taps=taps, dil=dil, center=center, want32=False)
+    res = torch.randn(M, N, device="cuda").half() if cls in ("res", "res_masked", "mrf") else None
+    valid = None
+    if cls == "pro":
+        kw.update(pro_slope=0.1, act=3, act_slope=0.1)
+    elif cls == "gelu":
+        kw.update(act=2)
+    elif cls in ("res", "res_masked"):
+        kw.update(res=res)
+        if cls == "res_masked":
+            valid = (torch.rand(M // 4, device="cuda") > 0.2).to(torch.uint8)          # one byte per 4 rows (valid_shift = 2)
+            kw.update(row_valid=valid, valid_shift=2)
+    elif cls == "mrf":
+        ma, mb = torch.randn(M, N, device="cuda").half(), torch.randn(M, N, device="cuda").half()
+        kw.update(res=res, add16=(ma, mb), scale=1.0 / 3.0, post_slope=0.1)
+    o_new, _ = _run_conv(lib, x, w, bias, **kw)
+    o_old, _ = _run_conv(lib, x, w, bias, dbg=4, **kw)
+    assert torch.equal(o_new.view(torch.int16), o_old.view(torch.int16)), name
+    # and against torch on a slice of rows (the whole tensor would take the CPU a while)
+    rows = slice(M // 2 - 512, M // 2 + 512)
+    xs = full[PAD + rows.start - PAD:PAD + rows.stop + PAD].float()
+    if cls == "pro":
+        xs = _lrelu(xs, 0.1)
+    ref = F.conv1d(xs.cpu().t().unsqueeze(0), w.float().cpu(), bias.cpu(), dilation=dil, padding=0)
+    ref = ref.squeeze(0).t()[PAD - center * dil:PAD - center * dil + 1024]
+    if cls == "pro":
+        ref = _lrelu(ref, 0.1)
+    elif cls == "gelu":
+        ref = F.gelu(ref)
+    elif cls in ("res", "res_masked"):
+        ref = ref + res[rows].float().cpu()
+        if valid is not None:
+            ref = ref * valid[rows.start // 4:rows.stop // 4].repeat_interleave(4).float().cpu()[:, None]
+    elif cls == "mrf":
+        ref = _lrelu((ref + res[rows].float().cpu()) / 3.0 + ma[rows].float().cpu() + mb[rows].float().cpu(), 0.1)
+    assert _rel(o_new[rows].float().cpu(), ref) < 8e-4, name
 
 
 def test_conv_gemm_activations_and_seq_bias(lib):
