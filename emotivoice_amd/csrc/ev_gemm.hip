@@ -12,8 +12,8 @@
 // the 16 rows of a ds_read_b128 fragment read hit distinct LDS slots at any tap offset.
 //
 // File map: generic LDS-transposed epilogue (every operand a run-time flag; fp32 / split kernels' fallback) ->
-// specialised straight-line epilogue (template flags, the frame-rate path) -> main conv-GEMM kernel + launch
-// heuristics -> split-precision kernels (fp16 hi/lo, 3 MFMAs per product: first generation 128 x 64 / 4 waves for few-tile
+// specialised straight-line epilogue (template flags, the frame-rate path) -> main conv-GEMM kernel -> phased 8-wave kernel
+// (LDS-DMA staging, alternating matrix / load phases: the large fp16 launches) + launch heuristics -> split-precision kernels (fp16 hi/lo, 3 MFMAs per product: first generation 128 x 64 / 4 waves for few-tile
 // token-rate GEMMs, second generation 256 x 128 / 8 waves for the EV_PREC_X3 frame-rate path) -> fused ResBlock-pair kernels
 // for C = 32 / C = 64 -> per-device setup.
 //
