@@ -57,10 +57,10 @@ def _device_style_embedder(config, gen):
         return None
     try:
         import torch
-        from transformers import AutoTokenizer
 
         from .simbert import StyleEncoderHIP
-        tokenizer = AutoTokenizer.from_pretrained(bert_path, local_files_only=True)            # :83
+        from .wordpiece import load_tokenizer
+        tokenizer = load_tokenizer(bert_path)             # :83 (vocab.txt -> the native WordPiece; else transformers' AutoTokenizer)
         model_ckpt = {k[7:]: v for k, v in torch.load(ckpt, map_location="cpu")["model"].items()}   # :63-66
         enc = StyleEncoderHIP(config, engine=gen._ensure_engine()).load_state_dict(model_ckpt, strict=False).eval()
     except Exception as e:                                  # noqa: BLE001 -- any missing piece means "no SimBERT available here"

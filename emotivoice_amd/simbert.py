@@ -6,7 +6,8 @@ end-to-end latency.  ``StyleEncoderHIP`` keeps the object prot
 ``StyleEncoder(config)``, ``load_state_dict(ckpt, strict=False)``, ``encoder(input_ids=..., token_type_ids=...,
 attention_mask=...)["pooled_output"]`` -- and computes ``pooled_output`` with ev_style_embed.  The four classification heads
 and ``style_embed_proj`` only exist for the style-encoder pre-training loss and never reach ``pooled_output``; their outputs
-are returned as None.  The tokenizer stays what it is in the reference (a host-side WordPiece lookup from transformers).
+are returned as None.  The tokenizer is a host-side WordPiece lookup as in the reference: ``emotivoice_amd.wordpiece`` from the
+checkpoint directory's ``vocab.txt`` (tested against transformers' BERT tokenizer), or any object with the same call protocol.
 """
 from __future__ import annotations
 
