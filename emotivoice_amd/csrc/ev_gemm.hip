@@ -961,10 +961,13 @@ static bool launch_phased_taps(const ConvGemmParams& p, int e, hipStream_t s) {
         case EPI_RARE_ACT | EPI_O16:
             if constexpr (BN == 128) { launch_phased_epi<TAPS, BN, EPI_RARE_ACT | EPI_O16>(p, s); return true; }
             return false;
+        case EPI_RES32 | EPI_O32:               // fp32 residual stream of the mel decoder (conv-FFN's second conv)
+            if constexpr (BN == 128 && TAPS == 3) { launch_phased_epi<TAPS, BN, EPI_RES32 | EPI_O32 | EPI_LEAN>(p, s); return true; }
+            return false;
         default: return false;
     }
 }
-// true if the launch was taken: fp16; N % 128 == 0 with 3 / 7 / 11 taps, or N % 64 == 0 with 11 taps; one of the four epilogue
+// true if the launch was taken: fp16; N % 128 == 0 with 3 / 7 / 11 taps, or N % 64 == 0 with 11 taps; one of the five epilogue
 // variants of the frame-rate path
 static bool launch_phased(const ConvGemmParams& p, int e, hipStream_t s) {
     if (p.M % PH_BM != 0 || p.K % 32 != 0 || (p.taps - 1) * p.dil > MAX_SPAN) return false;
@@ -992,6 +995,9 @@ static hipError_t phased_attr_taps() {
     r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, BN, EPI_RES16 | EPI_ADD16 | EPI_O16 | EPI_LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
     if constexpr (BN == 128) {
         r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, BN, EPI_RARE_ACT | EPI_O16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    }
+    if constexpr (BN == 128 && TAPS == 3) {
+        r = hipFuncSetAttribute((const void*)conv_gemm_phased_kernel<TAPS, BN, EPI_RES32 | EPI_O32 | EPI_LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
     }
     return e;
 }

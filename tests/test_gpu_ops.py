@@ -231,6 +231,7 @@ PHASED_CASES = [
     ("c64_k11_d1_mrf", 131072, 64, 64, 11, 1, "mrf"),
     ("ffn1_gelu", 8192, 384, 1536, 3, 1, "gelu"),
     ("ffn2_res", 22016, 1536, 384, 3, 1, "res"),
+    ("ffn2_res32_stream", 22016, 1536, 384, 3, 1, "res32"),      # the mel decoder's fp32 residual stream (in place)
     ("conv_pre_k7", 33024, 96, 512, 7, 1, "plain"),
 ]
 
@@ -250,6 +251,9 @@ def test_phased_kernel_matches_4_wave_kernel_bitwise(lib, case):
     center = (taps - 1) // 2
     kw = dict(dtype=0, taps=taps, dil=dil, center=center, want32=False)
     res = torch.randn(M, N, device="cuda").half() if cls in ("res", "res_masked", "mrf") else None
+    if cls == "res32":
+        res = torch.randn(M, N, device="cuda")
+        kw.update(res=res, want16=False, want32=True)
     valid = None
     if cls == "pro":
         kw.update(pro_slope=0.1, act=3, act_slope=0.1)
@@ -263,9 +267,10 @@ def test_phased_kernel_matches_4_wave_kernel_bitwise(lib, case):
     elif cls == "mrf":
         ma, mb = torch.randn(M, N, device="cuda").half(), torch.randn(M, N, device="cuda").half()
         kw.update(res=res, add16=(ma, mb), scale=1.0 / 3.0, post_slope=0.1)
-    o_new, _ = _run_conv(lib, x, w, bias, **kw)
-    o_old, _ = _run_conv(lib, x, w, bias, dbg=4, **kw)
-    assert torch.equal(o_new.view(torch.int16), o_old.view(torch.int16)), name
+    o_new = [o for o in _run_conv(lib, x, w, bias, **kw) if o is not None][0]
+    o_old = [o for o in _run_conv(lib, x, w, bias, dbg=4, **kw) if o is not None][0]
+    bits = torch.int16 if o_new.dtype == torch.float16 else torch.int32
+    assert torch.equal(o_new.view(bits), o_old.view(bits)), name
     # and against torch on a slice of rows (the whole tensor would take the CPU a while)
     rows = slice(M // 2 - 512, M // 2 + 512)
     xs = full[PAD + rows.start - PAD:PAD + rows.stop + PAD].float()
@@ -277,7 +282,7 @@ def test_phased_kernel_matches_4_wave_kernel_bitwise(lib, case):
         ref = _lrelu(ref, 0.1)
     elif cls == "gelu":
         ref = F.gelu(ref)
-    elif cls in ("res", "res_masked"):
+    elif cls in ("res", "res_masked", "res32"):
         ref = ref + res[rows].float().cpu()
         if valid is not None:
             ref = ref * valid[rows.start // 4:rows.stop // 4].repeat_interleave(4).float().cpu()[:, None]
