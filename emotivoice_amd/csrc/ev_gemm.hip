@@ -750,6 +750,16 @@ __device__ __forceinline__ void mfma_inplace(f32x4& c, const half8& a, const hal
 #ifndef EV_PH_ABLATE
 #define EV_PH_ABLATE 0
 #endif
+// EV_PH_TIMING (tuning builds): every wave accumulates, in SGPRs, the cycles it spends in each part of a step (s_memtime deltas) and lane 0
+// writes the seven sums to ((unsigned*)p.row_seq)[(block * 8 + wave) * 8 + k] at the end: k = 0 prologue, 1 vmcnt wait, 2 rest of the load
+// phase, 3 barrier after the load phase, 4 matrix phase, 5 barrier after the matrix phase, 6 epilogue (row_seq is unused by these launches).
+#ifdef EV_PH_TIMING
+#define EV_PH_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(); unsigned t_acc_[7] = {0, 0, 0, 0, 0, 0, 0};
+#define EV_PH_TICK(K) { const unsigned long long t_now_ = __builtin_readcyclecounter(); t_acc_[K] += (unsigned)(t_now_ - t_prev_); t_prev_ = t_now_; }
+#else
+#define EV_PH_T0()
+#define EV_PH_TICK(K)
+#endif
 // schedule switches (A/B builds): bit 0: staging requests issued inside the matrix phase, bit 1: fragment reads retired after the barrier
 #ifndef EV_PH_SCHED
 #define EV_PH_SCHED 3
@@ -775,6 +785,10 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wt = wave & 3, wc = wave >> 2;          // wc is also the phase group: waves w and w + 4 share a SIMD
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    EV_PH_T0()
+#ifdef EV_PH_TIMING
+    const int bid_raw_ = bid;
+#endif
 
     const int nN = p.N / BN;
     {
@@ -836,6 +850,7 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wc == 1) __builtin_amdgcn_s_barrier();
+    EV_PH_TICK(0)
 
     for (int kc = 0; kc < nkc; ++kc) {
         const bool more = kc + 1 < nkc;
@@ -861,7 +876,9 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
             if constexpr (DMA_IN_MMA) { if (u == 1 && more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); } \
             else { if (u <= 1 && more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
             if (u == 2) {                         // (fix-up before the fragment reads: its 24 transient registers and theirs never coexist)
+                EV_PH_TICK(2)
                 EV_PH_WAIT_VM
+                EV_PH_TICK(1)
                 if (more && pro) {
                     EV_PH_FIXUP((kc + 1) & 1)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -888,11 +905,13 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
                     asm volatile("" :: "v"(xp), "v"(wp));
                 }
             }
-            if (u != 2) { EV_PH_WAIT_VM }
+            if (u != 2) { EV_PH_TICK(2) EV_PH_WAIT_VM EV_PH_TICK(1) }
 #undef EV_PH_WAIT_VM
             if constexpr (!LGKM_AFTER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            EV_PH_TICK(2)
             if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            EV_PH_TICK(3)
             // (LGKM_AFTER: no explicit wait here -- hipcc's own counted lgkmcnt in front of each MFMA's first use retires the reads)
             __builtin_amdgcn_sched_barrier(0);
             // ---------------- matrix phase (+ the staging requests, in the shadow of the MFMAs)
@@ -920,7 +939,9 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            EV_PH_TICK(4)
             if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            EV_PH_TICK(5)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -931,6 +952,7 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wc == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+    EV_PH_TICK(5)
     if constexpr ((EV_PH_ABLATE & 16) == 0) {
         EV_TRACE_EPI_DUMMY
         gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC EV_TRACE_EPI_ARGS);
@@ -940,6 +962,15 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
 #pragma unroll
             for (int b = 0; b < MT; ++b) asm volatile("" :: "v"(acc[a][b]));
     }
+#ifdef EV_PH_TIMING
+    EV_PH_TICK(6)
+    if (p.row_seq && !p.seq_bias && lane == 0) {
+        unsigned* o_ = reinterpret_cast<unsigned*>(const_cast<int32_t*>(p.row_seq)) + ((size_t)bid_raw_ * 8 + wave) * 8;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o_[k] = t_acc_[k];
+        o_[7] = 0xC0FFEE;
+    }
+#endif
 }
 
 template <int TAPS, int BN, int EPI>
