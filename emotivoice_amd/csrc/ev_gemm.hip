@@ -760,7 +760,8 @@ __device__ __forceinline__ void mfma_inplace(f32x4& c, const half8& a, const hal
 #define EV_PH_T0()
 #define EV_PH_TICK(K)
 #endif
-// schedule switches (A/B builds): bit 0: staging requests issued inside the matrix phase, bit 1: fragment reads retired after the barrier
+// schedule switches (A/B builds): bit 0: staging requests issued inside the matrix phase, bit 1: fragment reads retired after the barrier,
+// bit 3: one barrier per step (group 0: between load and matrix phase, group 1: after the matrix phase)
 #ifndef EV_PH_SCHED
 #define EV_PH_SCHED 3
 #endif
@@ -774,7 +775,8 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
     constexpr int TPS = (BN == 64) ? 2 : 1;              // taps per step
     constexpr int U = (TAPS + TPS - 1) / TPS;            // steps per K-chunk
     constexpr int TC = BN / 2, MT = 4, NT = TC / 16;
-    constexpr bool DMA_IN_MMA = (EV_PH_SCHED & 1) != 0, LGKM_AFTER = (EV_PH_SCHED & 2) != 0;
+    constexpr bool DMA_IN_MMA = (EV_PH_SCHED & 1) != 0, LGKM_AFTER = (EV_PH_SCHED & 2) != 0, ONE_BAR = (EV_PH_SCHED & 8) != 0;
+    static_assert(!ONE_BAR || DMA_IN_MMA, "one barrier per step needs the staging requests inside the matrix phase");
     static_assert(BN == 128 || BN == 64, "tile width");
     static_assert(!LGKM_AFTER || DMA_IN_MMA, "a buffer may be re-targeted one phase after its last read only if that read was retired before the barrier");
     static_assert(U >= 3 && PH_SLABR >= BM + MAX_SPAN && 8 * 32 * (TC * 4 + 16) <= (int)PH_LDS, "pipeline depth / slab / epilogue scratch");
@@ -849,7 +851,7 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
     if (pro) { EV_PH_FIXUP(0) }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wc == 1) __builtin_amdgcn_s_barrier();
+    if (!ONE_BAR && wc == 1) __builtin_amdgcn_s_barrier();
     EV_PH_TICK(0)
 
     for (int kc = 0; kc < nkc; ++kc) {
@@ -910,7 +912,18 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
             if constexpr (!LGKM_AFTER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             EV_PH_TICK(2)
-            if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            if constexpr (ONE_BAR) {
+                // ONE barrier per step: group 0 between its load and matrix phase, group 1 after its matrix phase.  Between two barriers
+                // group 0 runs [matrix(s-1), load(s)] and group 1 [load(s), matrix(s)]: the alternation without the barrier after the
+                // matrix phase.  Group 0 retires its fragment reads before the barrier (its buffers are re-targeted by group 1's
+                // requests inside the interval that follows).
+                if (wc == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+                }
+            } else {
+                if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            }
             EV_PH_TICK(3)
             // (LGKM_AFTER: no explicit wait here -- hipcc's own counted lgkmcnt in front of each MFMA's first use retires the reads)
             __builtin_amdgcn_sched_barrier(0);
@@ -940,7 +953,8 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             EV_PH_TICK(4)
-            if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+            if constexpr (ONE_BAR) { if (wc == 1 && !(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier(); }
+            else { if (!(EV_PH_ABLATE & 8)) __builtin_amdgcn_s_barrier(); }
             EV_PH_TICK(5)
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -950,7 +964,7 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
 #undef EV_PH_FIXUP
     // drain the re-requested tail tiles, let group 1 catch up, then everybody may overwrite the staging buffers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wc == 0) __builtin_amdgcn_s_barrier();
+    if (!ONE_BAR && wc == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
     EV_PH_TICK(5)
     if constexpr ((EV_PH_ABLATE & 16) == 0) {
