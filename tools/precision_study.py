@@ -121,6 +121,12 @@ def main():
             "exact st2+st3": [F16, F16, F16, EX, EX],
             "exact st2+st3, split-w st0+st1": [dict(w=2, a=1, s=1)] * 3 + [EX, EX],
             "fp16 everywhere but fp32 MRF branches": [dict(w=1, a=1, s=1, mrf16=0)] * 5,
+            "fp16 weights + operands, fp32 storage (1 MFMA)": [dict(w=1, a=1, s=0)] * 5,
+            "split weights, fp16 operands, fp32 storage (2 MFMA)": [dict(w=2, a=1, s=0)] * 5,
+            "fp32 weights, fp16 operands, fp32 storage": [dict(w=0, a=1, s=0)] * 5,
+            "fp16 weights, fp32 operands, fp32 storage": [dict(w=1, a=0, s=0)] * 5,
+            "1 MFMA + fp32 storage in st0-st1, all fp16 in st2-st3": [dict(w=1, a=1, s=0)] * 3 + [F16, F16],
+            "all fp16 in st0-st1, 1 MFMA + fp32 storage in st2-st3": [F16] * 3 + [dict(w=1, a=1, s=0)] * 2,
         }
         for name, rec in cases.items():
             out = emulate(sd, r16(mel), shapes, rec)
