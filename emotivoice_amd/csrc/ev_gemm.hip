@@ -1553,9 +1553,23 @@ static void launch_split(const ConvGemmParams& p, hipStream_t s) {
 // HBM traffic per pair: read x once (+ the residual re-read, an L2 hit), write once -- vs 5 tensor passes layer-wise.
 __device__ char g_store_trash[64 * 64];     // masked lanes of the fused kernel's stores land here (no exec-masked branch)
 
+// Tuning builds only (build.py --variant <tag> EV_PAIR_ABLATE=<bits>): 1 no MFMAs, 2 no slab requests (the staged registers keep their
+// first tile), 4 no output stores, 8 no residual / MRF operand loads, 16 no block barriers.  Results are garbage by design.
+#ifndef EV_PAIR_ABLATE
+#define EV_PAIR_ABLATE 0
+#endif
+#define EV_PAIR_SYNC() { if (!(EV_PAIR_ABLATE & 16)) __syncthreads(); }
+#define EV_PAIR_MFMA(ACC, A, B) { if (!(EV_PAIR_ABLATE & 1)) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0); else asm volatile("" : "+v"(ACC) : "v"(A), "v"(B)); }
+
 // ACCMODE: 0 = none, 1 = fp32 accumulate-in (epi.acc32), 2 = two fp16 addends (epi.add16_a / add16_b)
-template <int K, int ACCMODE>
-__global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPairParams p) {
+// TWOB (k = 3, 7): two blocks per CU.  Ablations (profiles/r2_m_pair_c32_ablation.txt) showed the kernel insensitive to every single
+// ingredient -- no slab requests, no stores, no MFMAs, no barriers: 307 -> 267...299 us at k = 3 -- i.e. bound by the latency of its own
+// dependent instruction chain at two waves per SIMD, not by HBM.  The footprint shrinks to <= 71 KB: 320-row slabs, the transposing
+// scratch aliased onto the slab conv1 has finished with (16-row passes), the weights staged through the slab area before the first
+// tile (they live in registers afterwards; conv2's set stays in LDS at k = 7 to fit 128 VGPRs).
+// As built: k = 3 only; the weight fragments are read per tap (no resident sets: 128 VGPRs), the weights stay in LDS (69 KB per block).
+template <int K, int ACCMODE, bool TWOB>
+__global__ __launch_bounds__(512, TWOB ? 4 : 1) void resblock_pair_c32_kernel(const ResPairParams p) {
     // 8 waves x 32 rows, one persistent block per CU.  The memory instruction stream of the tile loop is straight-line: the
     // first version loaded row_valid bytes / MRF rows inside runtime-flag branches and an exec-masked third slab chunk, and
     // hipcc answered with s_waitcnt vmcnt(0) right after the next tile's slab prefetch (no prefetch at all) and between the
@@ -1566,15 +1580,22 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
     // while staging the slab (the raw residual rows are re-read from L2 at the top of the tile), xt / output math runs on
     // packed fp32 pairs, masks act on packed fp16 words and only for 32-row groups that contain invalid rows.
     constexpr int C = 32, H2 = (K - 1) / 2, BMO = 256 - 2 * H2;
-    constexpr int XROWS = 384, XTROWS = 272, XCH = XROWS * 4 / 512;
+    constexpr int XROWS = TWOB ? 320 : 384, XTROWS = 272, XCH = 3;
     constexpr int WBYTES = K * C * 64, XBYTES = XROWS * 64, XTBYTES = XTROWS * 64;
-    constexpr int EPITCH = C * 4 + 16, EBYTES = 32 * EPITCH;          // per-wave transpose scratch: 32 rows x 32 fp32
+    constexpr int EROWS = TWOB ? 16 : 32;                             // rows per transposing pass
+    constexpr int EPITCH = C * 4 + 16, EBYTES = EROWS * EPITCH;       // per-wave transpose scratch: EROWS rows x 32 fp32
+    // conv1's weight fragments (k * 2 x 16 B per lane) stay in registers for every tile of this persistent block, conv2's too
+    // up to k = 7 (k = 11: 176 VGPRs for both sets; conv2's set is then re-read from LDS per tile); TWOB (128 VGPRs): up to k = 3
+    constexpr bool W2_RESIDENT = TWOB ? false : (K <= 7);
+    constexpr bool W1_RESIDENT = !TWOB;                               // TWOB: both sets are read per tap (the 128-VGPR budget)
+    static_assert(!TWOB || (8 * EBYTES <= XBYTES && 256 + 2 * 5 * H2 + 2 * H2 <= XROWS), "TWOB aliasing");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [W1][W2][Xa 2 x slab][Xt][Es]; TWOB: no Es region -- the scratch is the slab of the tile being finished
     char* W1s = smem;
     char* W2s = smem + WBYTES;
-    char* Xa = smem + 2 * WBYTES;            // [2][XROWS][64]
-    char* Xt = Xa + 2 * XBYTES;              // [XTROWS][64]
-    char* Es = Xt + XTBYTES;                 // [8][EBYTES]
+    char* Xa = smem + 2 * WBYTES;                                     // [2][XROWS][64]
+    char* Xt = Xa + 2 * XBYTES;                                       // [XTROWS][64]
+    char* Es = Xt + XTBYTES;                                          // [8][EBYTES] (1 block / CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int h1 = H2 * p.dil;
@@ -1623,7 +1644,8 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
 #define EV_PAIR_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_PAIR_VROW(TILE) >= gmin && EV_PAIR_VROW(TILE) < gmax)
 
     uint4 xr0, xr1, xr2;
-    const int xd0 = swz(tid >> 2, tid & 3), xd1 = swz((tid + 512) >> 2, tid & 3), xd2 = swz((tid + 1024) >> 2, tid & 3);
+    // (TWOB: the rows past the 320-row slab all hold the last needed row -- see xrow2 -- so their chunks may land on row 319 together)
+    const int xd0 = swz(tid >> 2, tid & 3), xd1 = swz((tid + 512) >> 2, tid & 3), xd2 = swz(min((tid + 1024) >> 2, XROWS - 1), tid & 3);
     static_assert(XCH == 3, "three 16-B chunks per thread");
     const char* const xgt = xg + (tid & 3) * 16;
     const int xrow2 = min((tid >> 2) + 256, 255 + 2 * h1 + 2 * H2);
@@ -1648,6 +1670,13 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
 
     int tile = blockIdx.x;                    // grid <= ntiles
     unsigned long long vmask;
+    uint4 wf1[K][2], wf2[K][2];
+#define EV_PAIR_WFILL()                                                                                        \
+    _Pragma("unroll") for (int t = 0; t < K; ++t)                                                              \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+            if constexpr (W1_RESIDENT) wf1[t][a] = *reinterpret_cast<const uint4*>(W1s + swz(t * 32 + a * 16 + fr, fq)); \
+            if constexpr (W2_RESIDENT) wf2[t][a] = *reinterpret_cast<const uint4*>(W2s + swz(t * 32 + a * 16 + fr, fq)); \
+        }
     {
         uint8_t vb;
         EV_PAIR_GLOAD(tile)
@@ -1656,21 +1685,12 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
         vmask = EV_PAIR_VMASK(tile, vb);
     }
     __syncthreads();
-    // conv1's weight fragments (k * 2 x 16 B per lane) stay in registers for every tile of this persistent block, conv2's too
-    // up to k = 7 (k = 11: 176 VGPRs for both sets; conv2's set is then re-read from LDS per tile)
-    constexpr bool W2_RESIDENT = (K <= 7);
-    uint4 wf1[K][2], wf2[K][2];
-#pragma unroll
-    for (int t = 0; t < K; ++t)
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            wf1[t][a] = *reinterpret_cast<const uint4*>(W1s + swz(t * 32 + a * 16 + fr, fq));
-            if constexpr (W2_RESIDENT) wf2[t][a] = *reinterpret_cast<const uint4*>(W2s + swz(t * 32 + a * 16 + fr, fq));
-        }
+    EV_PAIR_WFILL()
+#undef EV_PAIR_WFILL
     int cur = 0;
     const int wrow0 = wave * 32 + fr;
-    char* es = Es + wave * EBYTES;
     for (; tile < ntiles; tile += gridDim.x) {
+        char* const es = (TWOB ? Xa + cur * XBYTES : Es) + wave * EBYTES;      // (TWOB: the slab conv1 has finished with)
         const int next = min(tile + (int)gridDim.x, ntiles - 1);      // clamped: the last prefetch of a block is never used
         const int m0 = tile * BMO;
         const int t_end = min(m0 + BMO, p.M);
@@ -1680,19 +1700,19 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int t = min(m0 + wave * 32 + it * 16 + er, t_end - 1);
-            resv[it] = *reinterpret_cast<const uint4*>(xg + (long)t * x_pitch + eg * 16);
+            if (!(EV_PAIR_ABLATE & 8)) resv[it] = *reinterpret_cast<const uint4*>(xg + (long)t * x_pitch + eg * 16); else resv[it] = make_uint4(t, it, lane, 0);
             if constexpr (ACCMODE == 1) {
                 const float* ap = e.acc32 + (long)t * e.ldacc + eco;
                 accin[it][0] = *reinterpret_cast<const float4*>(ap);
                 accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
             }
-            if constexpr (ACCMODE == 2) {        // the same 8 registers per row hold the two fp16 addends
+            if constexpr (ACCMODE == 2 && !(EV_PAIR_ABLATE & 8)) {        // the same 8 registers per row hold the two fp16 addends
                 *reinterpret_cast<uint4*>(&accin[it][0]) = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(e.add16_a) + (long)t * e.ldadd + eco);
                 *reinterpret_cast<uint4*>(&accin[it][1]) = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(e.add16_b) + (long)t * e.ldadd + eco);
             }
         }
         uint8_t vb_next;
-        EV_PAIR_GLOAD(next)
+        if (!(EV_PAIR_ABLATE & 2)) { EV_PAIR_GLOAD(next) }
         EV_PAIR_VLOAD(next, vb_next)
         __builtin_amdgcn_sched_barrier(0);    // hipcc otherwise sinks these requests below conv1, next to their use
         f32x4 acc[2][2];
@@ -1707,13 +1727,16 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
             for (int t = 0; t < K; ++t) {
                 const int r0 = wrow0 + t * p.dil;
                 const char* xp = Xb + r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
+                if constexpr (!W1_RESIDENT) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) wf1[t][a] = *reinterpret_cast<const uint4*>(W1s + swz(t * 32 + a * 16 + fr, fq));
+                }
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     uint4 xf = *reinterpret_cast<const uint4*>(xp + b * 16 * 64);
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf1[t][a]),
-                                                                           *reinterpret_cast<half8*>(&xf), acc[a][b], 0, 0, 0);
+                        EV_PAIR_MFMA(acc[a][b], *reinterpret_cast<half8*>(&wf1[t][a]), *reinterpret_cast<half8*>(&xf))
                 }
             }
         }
@@ -1735,9 +1758,9 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
                 *reinterpret_cast<uint2*>(Xt + swz(r1, co >> 3) + (co & 7) * 2) = w;
             }
         }
-        __syncthreads();
+        EV_PAIR_SYNC()
         // ---------------- conv2 (dilation 1): rows m0 + r2, reads Xt rows r2 + t
-        if constexpr (!W2_RESIDENT) {
+        if constexpr (!W2_RESIDENT && !TWOB) {
 #pragma unroll
             for (int t = 0; t < K; ++t)
 #pragma unroll
@@ -1751,13 +1774,16 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
         for (int t = 0; t < K; ++t) {
             const int r0 = wrow0 + t;
             const char* xp = Xt + r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
+            if constexpr (TWOB) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf2[t][a] = *reinterpret_cast<const uint4*>(W2s + swz(t * 32 + a * 16 + fr, fq));
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 uint4 xf = *reinterpret_cast<const uint4*>(xp + b * 16 * 64);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf2[t][a]),
-                                                                       *reinterpret_cast<half8*>(&xf), acc[a][b], 0, 0, 0);
+                    EV_PAIR_MFMA(acc[a][b], *reinterpret_cast<half8*>(&wf2[t][a]), *reinterpret_cast<half8*>(&xf))
             }
         }
         // ---------------- the next tile's slab goes to the idle buffer BEFORE this tile's stores are issued, so that its wait
@@ -1766,13 +1792,15 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
         EV_PAIR_SSTORE(cur ^ 1)
         const unsigned long long vmask_next = EV_PAIR_VMASK(next, vb_next);
         // ---------------- epilogue: transpose through the wave's scratch, then 16-byte row-contiguous stores
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (!TWOB) {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                *reinterpret_cast<f32x4*>(es + (b * 16 + fr) * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][b];
-        __builtin_amdgcn_wave_barrier();
+                for (int a = 0; a < 2; ++a)
+                    *reinterpret_cast<f32x4*>(es + (b * 16 + fr) * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][b];
+            __builtin_amdgcn_wave_barrier();
+        }
         const unsigned outmask = (unsigned)(vmask >> H2);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -1780,8 +1808,16 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
             const int t = m0 + wave * 32 + lr;
             const bool rowok = t < t_end;
             const bool valid = (outmask & (erbit << (it * 16))) != 0u;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + lr * EPITCH + eg * 32 + 16);
+            if constexpr (TWOB) {             // 16-row passes: row group `it` through the wave's 16-row scratch
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    *reinterpret_cast<f32x4*>(es + fr * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][it];
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int sr = TWOB ? er : lr;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + sr * EPITCH + eg * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + sr * EPITCH + eg * 32 + 16);
             f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
             const half2v* hh = reinterpret_cast<const half2v*>(&resv[it]);
 #pragma unroll
@@ -1816,11 +1852,12 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
 #pragma unroll
                 for (int q = 0; q < 4; ++q) h[q] = __builtin_convertvector(v[q], half2v);
                 o.x = valid ? o.x : 0u; o.y = valid ? o.y : 0u; o.z = valid ? o.z : 0u; o.w = valid ? o.w : 0u;
-                *reinterpret_cast<uint4*>(rowok ? reinterpret_cast<char*>(o16 + (long)t * e.ldo + eco) : trash) = o;
+                if (!(EV_PAIR_ABLATE & 4)) *reinterpret_cast<uint4*>(rowok ? reinterpret_cast<char*>(o16 + (long)t * e.ldo + eco) : trash) = o;
+                else asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
             }
         }
         vmask = vmask_next;
-        __syncthreads();
+        EV_PAIR_SYNC()
         cur ^= 1;
     }
 #undef EV_PAIR_GLOAD
@@ -1831,7 +1868,10 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_kernel(const ResPair
 #undef EV_PAIR_VMASK
 }
 
-static size_t pair_lds_bytes(int k) { return 2 * (size_t)k * 32 * 64 + 2 * 384 * 64 + 272 * 64 + 8 * 32 * (32 * 4 + 16); }
+static size_t pair_lds_bytes(int k, bool twob = false) {
+    if (twob) return 2 * (size_t)k * 32 * 64 + 2 * 320 * 64 + 272 * 64;
+    return 2 * (size_t)k * 32 * 64 + 2 * 384 * 64 + 272 * 64 + 8 * 32 * (32 * 4 + 16);
+}
 static constexpr size_t PAIR64_LDS_BYTES = 2 * 2 * (size_t)(3 * 64 * 64) + 2 * 2 * (size_t)(272 * 64) + 2 * (size_t)(272 * 64);
 
 // Per-device kernel state.  Kernels that use more than 64 KB of dynamic LDS need the opt-in attribute on EVERY device they are
@@ -1852,15 +1892,18 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
     const int h2 = (p.k - 1) / 2, bmo = 256 - 2 * h2;
     const int ntiles = (p.M + bmo - 1) / bmo;
     const int grid = ntiles < n_cu ? ntiles : n_cu;
-    const size_t lds = pair_lds_bytes(p.k);
-#define EV_PAIR_LAUNCH(KK)                                                                                          \
-    case KK:                                                                                                        \
-        if (p.epi.add16_a) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 2>), dim3(grid), dim3(512), lds, s, p);  \
-        else if (p.epi.acc32) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 1>), dim3(grid), dim3(512), lds, s, p); \
-        else hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 0>), dim3(grid), dim3(512), lds, s, p);             \
-        break;
+    static const char* one_env = getenv("EV_PAIR_1B");                   // "1": one block per CU for every k (A/B switch)
+    const bool twob = p.k <= 3 && !(one_env && one_env[0] == '1') && !(p.epi.reserved0 & 4) && ntiles >= 4 * n_cu;     // (reserved0 bit 2: in-process A/B)
+    const size_t lds = pair_lds_bytes(p.k, twob);
+    const int grid2 = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
+#define EV_PAIR_LAUNCH(KK, TB, G)                                                                                          \
+        if (p.epi.add16_a) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 2, TB>), dim3(G), dim3(512), lds, s, p);  \
+        else if (p.epi.acc32) hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 1, TB>), dim3(G), dim3(512), lds, s, p); \
+        else hipLaunchKernelGGL((resblock_pair_c32_kernel<KK, 0, TB>), dim3(G), dim3(512), lds, s, p);
     switch (p.k) {
-        EV_PAIR_LAUNCH(3) EV_PAIR_LAUNCH(7) EV_PAIR_LAUNCH(11)
+        case 3: if (twob) { EV_PAIR_LAUNCH(3, true, grid2) } else { EV_PAIR_LAUNCH(3, false, grid) } break;
+        case 7: EV_PAIR_LAUNCH(7, false, grid) break;
+        case 11: EV_PAIR_LAUNCH(11, false, grid) break;
         default: break;
     }
 #undef EV_PAIR_LAUNCH
@@ -2138,11 +2181,11 @@ int init_device_kernels(int device) {
     g_n_cu[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipSuccess;
     auto attr = [&](const void* fn, size_t bytes) { const hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (r != hipSuccess) e = r; };
-#define EV_PAIR_ATTR(KK)                                                         \
-    attr((const void*)resblock_pair_c32_kernel<KK, 0>, pair_lds_bytes(KK));      \
-    attr((const void*)resblock_pair_c32_kernel<KK, 1>, pair_lds_bytes(KK));      \
-    attr((const void*)resblock_pair_c32_kernel<KK, 2>, pair_lds_bytes(KK));
-    EV_PAIR_ATTR(3) EV_PAIR_ATTR(7) EV_PAIR_ATTR(11)
+#define EV_PAIR_ATTR(KK, TB)                                                             \
+    attr((const void*)resblock_pair_c32_kernel<KK, 0, TB>, pair_lds_bytes(KK, TB));      \
+    attr((const void*)resblock_pair_c32_kernel<KK, 1, TB>, pair_lds_bytes(KK, TB));      \
+    attr((const void*)resblock_pair_c32_kernel<KK, 2, TB>, pair_lds_bytes(KK, TB));
+    EV_PAIR_ATTR(3, false) EV_PAIR_ATTR(7, false) EV_PAIR_ATTR(11, false) EV_PAIR_ATTR(3, true)
 #undef EV_PAIR_ATTR
     attr((const void*)resblock_pair_c64_kernel<3, 0>, PAIR64_LDS_BYTES);
     attr((const void*)resblock_pair_c64_kernel<3, 1>, PAIR64_LDS_BYTES);
