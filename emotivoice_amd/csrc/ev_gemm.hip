@@ -700,21 +700,24 @@ static void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
 //   * 8 waves per block, two blocks per CU (4 waves per SIMD, <= 128 VGPRs): tile 256 x 128, each wave owns 64 x 64 outputs
 //     (16 accumulator tiles, 16 MFMAs against 8 fragment reads per step);
 //   * waves 0-3 (one per SIMD) and waves 4-7 (their SIMD partners) run the same code one barrier apart: while one group issues
-//     the 16 MFMAs of step s (s_setprio 1), the other one reads the fragments of its next step and issues its share of the
-//     staging traffic; a barrier ends every phase.  On every SIMD exactly one wave of each resident block wants the matrix pipe
-//     at any time;
+//     the 16 MFMAs of step s (s_setprio 1) -- and, in their shadow, its share of the staging requests --, the other one reads the
+//     fragments of its next step; a barrier ends every phase.  On every SIMD exactly one wave of each resident block wants the
+//     matrix pipe at any time;
 //   * staging is LDS-DMA only (global_load_lds_dwordx4, issued through inline asm so that hipcc neither drains vmcnt in front
 //     of the fragment reads nor sees staging registers): the weight tile of step s + 3 (8 KB, one 1-KB piece per wave) into a
 //     ring of four buffers, the activation slab of K-chunk kc + 1 (384 rows x 64 B, three pieces per wave) at the first tap of
 //     chunk kc.  The 64-byte-pitch XOR swizzle of conv_gemm_kernel is applied on the SOURCE side (lane l of a 16-row piece fetches
 //     part (l & 3) ^ ((l >> 3) & 3) of row l >> 2; the DMA writes lane-linear), the fragment reads are unchanged;
-//   * waits are counted, never 0 inside the loop: VMEM returns in order, so "everything this wave issued two phases ago has
-//     landed" is s_waitcnt vmcnt(#pieces issued in this and the previous load phase), a compile-time number because the tap
-//     loop is unrolled (TAPS is a template parameter); the piece is visible to the other waves after the phase's barrier and is
-//     first read two barriers later;
+//   * waits are counted, never 0 inside the loop: VMEM returns in order, so "the pieces this wave requested two matrix phases ago
+//     have landed" is s_waitcnt vmcnt(#pieces requested in the latest matrix phase) in the load phase, a compile-time number because
+//     the tap loop is unrolled (TAPS is a template parameter); the piece is visible to the other waves after the phase's barrier
+//     and is first read two barriers later;
 //   * leaky-relu of the consumer side (pro_lrelu) cannot be applied in flight any more: every wave fixes up its own three slab
 //     pieces in place (ds_read / v_pk_mul + v_pk_max / ds_write) right after the wait that retires them, once per K-chunk;
-//   * a buffer is re-targeted by a DMA only after the barrier that follows the lgkmcnt(0) of its last reader.
+//   * a buffer is re-targeted by a DMA only after a barrier that follows the retirement of its last reader's fragment reads (they
+//     retire in front of that reader's first MFMA, one phase before the earliest request for the buffer is issued).
+// EV_PH_SCHED selects the earlier schedules for A/B builds (requests in the load phase, reads retired before the barrier, one barrier
+// per step): all bit-identical and within 1 % of each other.
 // Same accumulation order per output element as conv_gemm_kernel (K-chunks outer, taps inner, one 32-deep MFMA per step) and the
 // same epilogue functions: results are bit-identical to the 4-wave kernel (tests/test_gpu_ops.py), so the batch-invariance
 // guarantee is untouched by which kernel a launch takes.
