@@ -385,15 +385,26 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
 #pragma unroll
         for (int nq = 0; nq < 2; ++nq) {
             float mx = -INFINITY;
+            if (more) {                       // only the last key tile can reach past the utterance: no per-element compare elsewhere
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[nq][kt][r] * scale2;
-                    if (key0 + kt * 16 + r >= len) v = -INFINITY;
-                    s[nq][kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = s[nq][kt][r] * scale2;
+                        s[nq][kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = s[nq][kt][r] * scale2;
+                        if (key0 + kt * 16 + r >= len) v = -INFINITY;
+                        s[nq][kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mn = fmaxf(m[nq], mx);
