@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVHIP_LIB", os.path.join(_HERE, "csrc", "libevhip.so"))
 EV_ABI_VERSION = 1
-EV_PREC_F16, EV_PREC_F32, EV_PREC_X3 = 0, 1, 2
+EV_PREC_F16, EV_PREC_F32, EV_PREC_X3, EV_PREC_MX = 0, 1, 2, 3
 EV_FLAG_DEVICE_INPUTS, EV_FLAG_NO_VOCODER, EV_FLAG_WANT_INT16, EV_FLAG_FORCED_DURATIONS = 1, 2, 4, 8
 
 
@@ -66,6 +66,8 @@ class ev_conv_gemm_desc(C.Structure):
         ("post_slope", C.c_float), ("out16", C.c_void_p), ("out32", C.c_void_p), ("ldo", C.c_int),
         ("out32_before_post", C.c_int), ("reserved0", C.c_int),
         ("add16_a", C.c_void_p), ("add16_b", C.c_void_p), ("ldadd", C.c_int), ("reserved1", C.c_int),
+        ("W_mx", C.c_void_p), ("mx_scratch", C.c_void_p), ("mx_scratch_size", C.c_size_t),
+        ("mx_x4", C.c_void_p * 2), ("mx_xs", C.c_void_p * 2), ("mx_xs_stride", C.c_uint), ("reserved2", C.c_int),
     ]
 
 
@@ -99,6 +101,7 @@ SIGNATURES = {
     "ev_style_load_weights": (C.c_int, [_P, C.POINTER(ev_bert_config), _P, C.c_size_t]),
     "ev_style_embed": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_uint32, _P]),
     "ev_op_conv_gemm": (C.c_int, [C.POINTER(ev_conv_gemm_desc), _P]),
+    "ev_op_mx_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ev_op_resblock_pair_c32": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_resblock_pair_c64": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_layernorm": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_float, _P, _P]),

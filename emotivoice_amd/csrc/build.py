@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ev_gemm.hip", "ev_misc.hip", "ev_engine.cpp"]
-HEADERS = ["ev_kernels.h", "../../include/evhip.h", "../../include/evhip_ops.h"]
+HEADERS = ["ev_kernels.h", "ev_gemm_mx.h", "../../include/evhip.h", "../../include/evhip_ops.h"]
 OUT = os.path.join(HERE, "libevhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

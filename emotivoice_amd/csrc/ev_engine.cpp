@@ -1378,11 +1378,13 @@ int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* stream) {
     memcpy(&p, d, sizeof p);
     const int es = p.dtype == DT_F16 ? 2 : 4;
     if (p.M % ROW_ALIGN || p.N % 32 || (p.K * es) % 64 || (p.taps - 1) * p.dil > 64) return -2;
-    if (p.dtype == DT_F32S && (p.K % 32 || !p.W_lo)) return -2;
+    if ((p.dtype == DT_F32S || p.dtype == DT_MX) && (p.K % 32 || !p.W_lo)) return -2;
+    if (p.dtype == DT_MX && p.W_mx && (!p.mx_scratch || p.mx_scratch_size < mx_scratch_bytes(p.M, p.K))) return -2;
     if (p.pro_lrelu && !(p.pro_slope >= 0.f && p.pro_slope <= 1.f)) return -2;
     launch_conv_gemm(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+size_t ev_op_mx_scratch_bytes(int M, int K) { return mx_scratch_bytes(M, K); }
 int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* stream) {
     static_assert(sizeof(ev_res_pair_desc) == sizeof(ResPairParams), "descriptor layout must match ResPairParams");
     ResPairParams p;

@@ -2177,6 +2177,8 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
 #undef EV_P64_VMASK
 }
 
+#include "ev_gemm_mx.h"
+
 int init_device_kernels(int device) {
     if (device < 0 || device >= 64) return -1;
     hipDeviceProp_t prop;
@@ -2195,6 +2197,7 @@ int init_device_kernels(int device) {
     attr((const void*)resblock_pair_c64_kernel<3, 2>, PAIR64_LDS_BYTES);
     if (x3_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (phased_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
+    if (mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     g_dev_ready[device] = (e == hipSuccess);
     return e == hipSuccess ? 0 : -1;
 }
@@ -2214,7 +2217,10 @@ void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {
     (void)device_cus();          // per-device large-LDS opt-in for the per-kernel entry points that run without a handle
     if (p.dtype == DT_F16) launch_dt<_Float16>(p, s);
     else if (p.dtype == DT_F32S) launch_split(p, s);
-    else launch_dt<float>(p, s);
+    else if (p.dtype == DT_MX) {
+        if (mx_eligible(p)) launch_mx(p, s);
+        else { ConvGemmParams q = p; q.dtype = DT_F32S; launch_split(q, s); }      // same operands, three fp16 MFMAs per product
+    } else launch_dt<float>(p, s);
 }
 
 }  // namespace ev

@@ -1,0 +1,358 @@
+// "MX" conv-GEMM: fp32-class activations, every product evaluated as
+//
+//        x.w  =  xh.wh                         one fp16 MFMA            (v_mfma_f32_16x16x32_f16)
+//              + Q(wl).Q(xh) + Q(wh).Q(xl)     two block-scaled fp4 MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4: K = 128 per instruction,
+//                                              4x the fp16 rate, one E8M0 scale per lane = per 32 consecutive K elements)
+//
+// with xh = fp16(x), xl = x - xh (and the same for w).  The cross terms are 2^-11 of the result, so fp4's ~2 significant bits turn
+// fp16's 3e-4 per-product rounding into ~3e-5: the generator's waveform error drops from 2.3e-3 (fp16 operands) to 3.5e-4
+// (tools/precision_study_mx.py), inside the 1e-3 contract, for 1.5 MFMA-units instead of the split-precision mode's 3
+// (tools/mfma_ubench.hip: 64 f16 + 32 MX MFMAs per K = 128 sustain 1.16-1.29 PF/s algorithmic on random operands, register-resident,
+// against 1.96 PF/s for the fp16 MFMAs alone and 0.65 for three of them).
+//
+// Included by ev_gemm.hip (inside namespace ev): re-uses its LDS-DMA helpers, swizzle and epilogues.
+//
+// Operand planes.  A 128-channel chunk of a row is 64 bytes of fp4 codes -- byte-for-byte the geometry of a 32-channel fp16 chunk -- so
+// the phased kernel's whole staging machinery (384-row slabs of 64-byte rows, source-side XOR swizzle, weight ring of four 8-KB
+// tiles, counted vmcnt) carries over unchanged, and the kernel is the SAME pipeline run over three operand pairs back to back:
+//        pass 0:  A = wh (fp16)   B = xh (fp16)    K / 32 chunks, f16 MFMA
+//        pass 1:  A = Q(wl) fp4   B = Q(xh) fp4    K / 128 chunks, MX MFMA
+//        pass 2:  A = Q(wh) fp4   B = Q(xl) fp4    K / 128 chunks, MX MFMA
+// as one continuous step sequence (no drain between passes), all three into the same fp32 accumulators.
+// Scales: activations one byte per (row, 32 channels), stored chunk-major [K/128][rows][4]; weights one byte per (output channel,
+// tap, 128 channels), stored [N/128][K/128][taps][128].  Per chunk they are 1.3 KB + taps x 128 B and travel in the third slab piece
+// of waves 4-7, which in the fp16 pass only re-reads the slab's last row (rows 320..383 of a slab buffer are never read by a
+// fragment): same piece count per wave in every pass, so every vmcnt immediate stays what it was.
+//
+// Activation planes are produced by mx_planes_kernel (leaky-relu of the consumer, fp16 hi plane, fp4 codes of hi and of the fp32
+// remainder, scales) from the fp32 tensor; fusing that into the producer's epilogue is the next step.
+#pragma once
+
+static constexpr int MX_SLACK = 64;          // readable rows in front of / behind every plane (the conv halo of the first / last tile)
+
+__host__ __device__ inline size_t mx_align256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct MxPlaneLayout { size_t h, x4h, x4l, sh, sl, total; size_t rows; };
+static MxPlaneLayout mx_layout(int M, int K) {
+    MxPlaneLayout L;
+    L.rows = (size_t)M + 2 * MX_SLACK;
+    size_t o = 0;
+    L.h = o; o = mx_align256(o + L.rows * K * 2);
+    L.x4h = o; o = mx_align256(o + L.rows * (K / 2));
+    L.x4l = o; o = mx_align256(o + L.rows * (K / 2));
+    L.sh = o; o = mx_align256(o + (size_t)(K / 128) * L.rows * 4);
+    L.sl = o; o = mx_align256(o + (size_t)(K / 128) * L.rows * 4);
+    L.total = o;
+    return L;
+}
+size_t mx_scratch_bytes(int M, int K) { return mx_layout(M, K).total; }
+
+// ---- fp32 [M][K] -> planes.  One thread = 8 consecutive channels of a row (one 16-byte store of the fp16 plane, one dword of each
+// code plane); the four threads of a 32-channel block agree on the block maxima through two xor-shuffles.
+__device__ __forceinline__ unsigned mx_fp4_code(float y) {          // |y| <= 6 after scaling (larger saturates), round to nearest even
+    const float a = fabsf(y);
+    unsigned c = (a > 0.25f) + (a >= 0.75f) + (a > 1.25f) + (a >= 1.75f) + (a > 2.5f) + (a >= 3.5f) + (a > 5.0f);
+    return c | ((__float_as_uint(y) >> 28) & 8u);
+}
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {     // E8M0 byte of 2^(floor(log2 amax) - 2), clamped to [1, 254]
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 2;
+    return (unsigned)min(max(e, 1), 254);
+}
+__global__ __launch_bounds__(256) void mx_planes_kernel(const float* __restrict__ A, int lda, int M, int K, int pro, float slope,
+                                                        __half* __restrict__ H, uint8_t* __restrict__ x4h, uint8_t* __restrict__ x4l,
+                                                        uint8_t* __restrict__ sh, uint8_t* __restrict__ sl, unsigned s_stride) {
+    const int tpr = K >> 3;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = gid / tpr;
+    const int g = (int)(gid - row * tpr);
+    if (row >= M) return;
+    const float4 a0 = *reinterpret_cast<const float4*>(A + row * lda + g * 8), a1 = *reinterpret_cast<const float4*>(A + row * lda + g * 8 + 4);
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    if (pro) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+    }
+    half8 hv;
+    float hf[8], lf[8], mh = 0.f, ml = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hv[e] = h; hf[e] = (float)h; lf[e] = v[e] - hf[e];
+        mh = fmaxf(mh, fabsf(hf[e])); ml = fmaxf(ml, fabsf(lf[e]));
+    }
+    mh = fmaxf(mh, __shfl_xor(mh, 1)); mh = fmaxf(mh, __shfl_xor(mh, 2));
+    ml = fmaxf(ml, __shfl_xor(ml, 1)); ml = fmaxf(ml, __shfl_xor(ml, 2));
+    const unsigned bh = mx_scale_byte(mh), bl = mx_scale_byte(ml);
+    const float ih = __uint_as_float((254u - bh) << 23), il = __uint_as_float((254u - bl) << 23);
+    unsigned ch = 0, cl = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ch |= mx_fp4_code(hf[e] * ih) << (4 * e); cl |= mx_fp4_code(lf[e] * il) << (4 * e); }
+    *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(H) + row * K + g * 8) = hv;
+    *reinterpret_cast<unsigned*>(x4h + row * (K >> 1) + g * 4) = ch;
+    *reinterpret_cast<unsigned*>(x4l + row * (K >> 1) + g * 4) = cl;
+    if ((g & 3) == 0) {
+        const long so = (long)(g >> 4) * s_stride + row * 4 + ((g >> 2) & 3);
+        sh[so] = (uint8_t)bh; sl[so] = (uint8_t)bl;
+    }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// A = 16 output channels x 128 K (fp4: 16 bytes per lane, lane = (row l & 15, 32-element K block l >> 4)), B likewise for 16 time steps;
+// byte 0 of sa / sb is the lane's E8M0 block scale.  In place, as mfma_inplace.
+__device__ __forceinline__ void mfma_mx_inplace(f32x4& c, const uint4& a, const uint4& b, int sa, int sb) {
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                 : "+v"(c) : "v"(*reinterpret_cast<const u32x4*>(&a)), "v"(*reinterpret_cast<const u32x4*>(&b)), "v"(sa), "v"(sb));
+}
+
+// one chunk's operand sources: uniform bases (SGPR pairs), the shift that turns the fp4-plane lane offsets into fp16-plane ones
+struct MxChunk { const char* xb; const char* wb; const char* sc; unsigned sh; };
+
+// LDS of a slab buffer: rows 0..319 of 64 B (fragments), [20 KB, 22 KB): activation scales (4 B per slab row, from row (m0 - c d) & ~3),
+// [22 KB, 24 KB): weight scales [tap][128]
+static constexpr int MX_XS_OFF = 20480, MX_WS_OFF = 22528;
+
+template <int TAPS, int EPI>
+__global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmParams p) {
+    constexpr int BM = PH_BM, XBUF = PH_XBUF, WBUF = PH_WBUF, U = TAPS, TC = 64, MT = 4, NT = 4;
+    static_assert(U >= 3 && TAPS * 128 <= 2048 && PH_SLABR >= BM + MAX_SPAN + 64, "pipeline depth / scale pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Xs = smem;                 // [2][SLABR][64]
+    char* const Ws = smem + 2 * XBUF;      // [4][8 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave & 3, wc = wave >> 2;          // wc is also the phase group: waves w and w + 4 share a SIMD
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x, nN = p.N >> 7;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (bid / nN) * BM, nt = bid % nN, n0 = nt * 128;
+    const int nkc16 = p.K >> 5, nkc4 = p.K >> 7, nq = nkc16 + 2 * nkc4;
+    const unsigned K2 = (unsigned)p.K >> 1;                // row / tap pitch of a fp4 plane in bytes; the fp16 planes' is 4 x that
+    const unsigned wrp4 = K2 * TAPS;
+    const int row0 = m0 - p.center * p.dil;                // first slab row (negative for the first tile: slack rows)
+    const int row0a = row0 & ~3, soff = row0 - row0a;      // the scale run starts on a 16-byte boundary
+
+    const int prow = lane >> 2;
+    const unsigned pp16 = (unsigned)(((lane & 3) ^ ((lane >> 3) & 3)) << 4);
+    const unsigned wrK = __umul24((unsigned)(wave * 16 + prow), wrp4);
+    unsigned rsK[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = (wave + 8 * i) * 16 + prow, rs = min(r, BM + (TAPS - 1) * p.dil - 1);
+        rsK[i] = __umul24((unsigned)rs, K2);
+    }
+    // lane offset of this wave's scale piece (waves 4, 5: activation scales; 6, 7: weight scales), clamped inside the run
+    // (activation run: 4 bytes per slab row from row0a, rounded up to 16; nothing beyond it is requested: the planes have 64 slack rows)
+    const int xs_run = ((BM + (TAPS - 1) * p.dil + soff) * 4 + 15) & ~15;
+    unsigned scv;
+    if (wave == 4) scv = min(lane * 16, xs_run - 16);
+    else if (wave == 5) scv = min(1024 + lane * 16, xs_run - 16);
+    else if (wave == 6) scv = min(lane * 16, TAPS * 128 - 16);
+    else scv = min(1024 + lane * 16, TAPS * 128 - 16);
+
+    const char* const wmx = reinterpret_cast<const char*>(p.W_mx);
+    const size_t nw4 = (size_t)p.N * wrp4, nws = (size_t)nN * nkc4 * TAPS * 128;
+    const char* const xb16 = uniform_ptr(reinterpret_cast<const char*>(p.A) + (long)row0 * (long)(4 * K2));
+    const char* const xb4h = uniform_ptr(reinterpret_cast<const char*>(p.mx_x4[0]) + (long)row0 * (long)K2);
+    const char* const xb4l = uniform_ptr(reinterpret_cast<const char*>(p.mx_x4[1]) + (long)row0 * (long)K2);
+    const char* const wb16 = uniform_ptr(reinterpret_cast<const char*>(p.W) + (long)n0 * (long)(4 * wrp4));
+    const char* const wb4l = uniform_ptr(wmx + (long)n0 * (long)wrp4);
+    const char* const wb4h = uniform_ptr(wmx + nw4 + (long)n0 * (long)wrp4);
+    const char* const sxh = uniform_ptr(reinterpret_cast<const char*>(p.mx_xs[0]) + (long)row0a * 4);
+    const char* const sxl = uniform_ptr(reinterpret_cast<const char*>(p.mx_xs[1]) + (long)row0a * 4);
+    const char* const swl = uniform_ptr(wmx + 2 * nw4 + (size_t)nt * nkc4 * TAPS * 128);
+    const char* const swh = uniform_ptr(wmx + 2 * nw4 + nws + (size_t)nt * nkc4 * TAPS * 128);
+    const unsigned xs_stride = p.mx_xs_stride;
+
+    auto chunk_of = [&](int q) -> MxChunk {
+        MxChunk c;
+        if (q < nkc16) { c.xb = xb16 + (unsigned)q * 64u; c.wb = wb16 + (unsigned)q * 64u; c.sc = nullptr; c.sh = 2; return c; }
+        q -= nkc16;
+        const bool second = q >= nkc4;
+        const unsigned kc = second ? q - nkc4 : q;
+        c.xb = (second ? xb4l : xb4h) + kc * 64u;
+        c.wb = (second ? wb4h : wb4l) + kc * 64u;
+        c.sc = wave < 6 ? (second ? sxl : sxh) + kc * xs_stride : (second ? swh : swl) + kc * (unsigned)(TAPS * 128);      // (32-bit products: scalar)
+        c.sh = 0;
+        return c;
+    };
+
+    const unsigned xdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024), wdst = xdst + 2 * XBUF;
+    // weight tile of tap US of chunk C -> ring slot SLOT; slab piece I of chunk C -> slab buffer BUF
+#define EV_MX_ISSUE_W(C, US, SLOT) glds16((C).wb + (unsigned)(US) * (K2 << (C).sh), (wrK << (C).sh) + pp16, wdst + (unsigned)(SLOT) * WBUF);
+#define EV_MX_ISSUE_X(C, BUF, I)                                                                                   \
+    {                                                                                                              \
+        if ((I) == 2 && (C).sh == 0 && wave >= 4) glds16((C).sc, scv, xdst + (unsigned)(BUF) * XBUF + (I) * 8192); \
+        else glds16((C).xb, (rsK[I] << (C).sh) + pp16, xdst + (unsigned)(BUF) * XBUF + (I) * 8192);                 \
+    }
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int woff = swz(wc * TC + fr, fq);
+    const int ws_off = MX_WS_OFF + wc * TC + fr;                       // + tap * 128 + a * 16
+    const int xs_off = MX_XS_OFF + (wt * 64 + fr + soff) * 4 + fq;     // + (tap * dil + b * 16) * 4
+
+    MxChunk cur = chunk_of(0), nxt = chunk_of(nq > 1 ? 1 : 0);
+    EV_MX_ISSUE_X(cur, 0, 0)
+    EV_MX_ISSUE_X(cur, 0, 1)
+    EV_MX_ISSUE_X(cur, 0, 2)
+    EV_MX_ISSUE_W(cur, 0, 0)
+    EV_MX_ISSUE_W(cur, 1, 1)
+    EV_MX_ISSUE_W(cur, 2, 2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wc == 1) __builtin_amdgcn_s_barrier();
+
+    // One (chunk, tap) step; see conv_gemm_phased_body for the schedule (requests inside the matrix phase, fragment reads retired by the
+    // compiler's own lgkmcnt in front of the first MFMA, two barriers per step).  MX: true in the fp4 passes.
+#define EV_MX_STEP(MX, u)                                                                                               \
+    {                                                                                                                   \
+        const int s = sbase + (u);                                                                                      \
+        const bool in_cur = ((u) + 3 < U) || !more;                                                                     \
+        const int u3 = ((u) + 3 < U) ? (u) + 3 : (more ? (u) + 3 - U : U - 1);                                          \
+        uint4 xf[MT], wf[NT];                                                                                           \
+        int xsc[MT], wsc[NT];                                                                                           \
+        {                                                                                                               \
+            const int row0_ = wt * 64 + fr + (u) * dil_;                                                                \
+            const char* xp = Xb + row0_ * 64 + ((fq ^ ((row0_ >> 1) & 3)) << 4);                                        \
+            const char* wp = Ws + (s & 3) * WBUF + woff;                                                                \
+            _Pragma("unroll") for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4*>(wp + a * 1024);      \
+            _Pragma("unroll") for (int b = 0; b < MT; ++b) xf[b] = *reinterpret_cast<const uint4*>(xp + b * 1024);      \
+            if constexpr (MX) {                                                                                         \
+                _Pragma("unroll") for (int a = 0; a < NT; ++a) wsc[a] = *reinterpret_cast<const uint8_t*>(Xb + ws_off + (u) * 128 + a * 16); \
+                _Pragma("unroll") for (int b = 0; b < MT; ++b) xsc[b] = *reinterpret_cast<const uint8_t*>(Xb + xs_off + ((u) * dil_ + b * 16) * 4); \
+            }                                                                                                           \
+        }                                                                                                               \
+        if ((u) == 1 && more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        _Pragma("unroll") for (int a = 0; a < NT; ++a) {                                                                \
+            _Pragma("unroll") for (int b = 0; b < MT; ++b) {                                                            \
+                if constexpr (MX) mfma_mx_inplace(acc[a][b], wf[a], xf[b], wsc[a], xsc[b]);                             \
+                else mfma_inplace(acc[a][b], *reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf[b]));     \
+                const int idx = a * MT + b;                                                                             \
+                if (idx == 2) { if (in_cur) { EV_MX_ISSUE_W(cur, u3, (s + 3) & 3) } else { EV_MX_ISSUE_W(nxt, u3, (s + 3) & 3) } } \
+                if ((u) == 0 && more) {                                                                                 \
+                    if (idx == 4) { EV_MX_ISSUE_X(nxt, (q + 1) & 1, 0) }                                                \
+                    if (idx == 5) { EV_MX_ISSUE_X(nxt, (q + 1) & 1, 1) }                                                \
+                    if (idx == 6) { EV_MX_ISSUE_X(nxt, (q + 1) & 1, 2) }                                                \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+
+    // two loops, not one loop with an fp16 / fp4 branch: with both bodies behind a branch hipcc gave the accumulators different registers on the
+    // two paths (64 moves per chunk and 80-150 spilled registers); back to back they simply flow from the first loop into the second
+    int sbase = 0, q = 0;
+    for (; q < nkc16; ++q) {
+        const bool more = q + 1 < nq;
+        const char* const Xb = Xs + (q & 1) * XBUF;
+        int dil_ = p.dil;
+        asm volatile("" : "+s"(dil_));            // (opaque per chunk: keeps hipcc from hoisting the fragment addresses of all taps)
+#pragma unroll
+        for (int u = 0; u < U; ++u) EV_MX_STEP(false, u)
+        sbase += U;
+        cur = nxt;
+        nxt = chunk_of(q + 2 < nq ? q + 2 : nq - 1);
+    }
+    for (; q < nq; ++q) {
+        const bool more = q + 1 < nq;
+        const char* const Xb = Xs + (q & 1) * XBUF;
+        int dil_ = p.dil;
+        asm volatile("" : "+s"(dil_));
+#pragma unroll
+        for (int u = 0; u < U; ++u) EV_MX_STEP(true, u)
+        sbase += U;
+        cur = nxt;
+        nxt = chunk_of(q + 2 < nq ? q + 2 : nq - 1);
+    }
+#undef EV_MX_STEP
+#undef EV_MX_ISSUE_W
+#undef EV_MX_ISSUE_X
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wc == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC);
+    else {
+        EV_TRACE_EPI_DUMMY
+        gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC EV_TRACE_EPI_ARGS);
+    }
+}
+
+template <int TAPS, int EPI>
+static void launch_mx_epi(const ConvGemmParams& p, hipStream_t s) {
+    const int grid = (p.M / PH_BM) * (p.N / 128);
+    hipLaunchKernelGGL((conv_gemm_mx_kernel<TAPS, EPI>), dim3(grid), dim3(512), PH_LDS, s, p);
+}
+template <int TAPS>
+static void launch_mx_taps(const ConvGemmParams& p, hipStream_t s) {
+    // the split-precision path's epilogue variants (fp32 output); the operand-heavy ones one pass at a time (128 registers)
+    const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
+    const bool odd_slope = p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f);
+    const bool o32 = p.out32 && !p.out16 && !p.out32_before_post && !p.post_lrelu;
+    const bool plain = !p.seq_bias && !p.add16_a && o32 && !odd_slope;
+    const bool res32 = p.res && p.res_dtype == DT_F32;
+    if (plain && !p.acc32 && !p.res && !rare_act) return launch_mx_epi<TAPS, EPI_O32>(p, s);
+    if (plain && !p.acc32 && !p.res && rare_act) return launch_mx_epi<TAPS, EPI_RARE_ACT | EPI_O32>(p, s);
+    if (plain && !p.acc32 && res32 && !rare_act) return launch_mx_epi<TAPS, EPI_RES32 | EPI_O32 | EPI_LEAN>(p, s);
+    if (plain && p.acc32 && res32 && !rare_act) return launch_mx_epi<TAPS, EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN>(p, s);
+    launch_mx_epi<TAPS, EPI_GENERIC>(p, s);
+}
+template <int TAPS>
+static hipError_t mx_attr_taps() {
+    hipError_t e = hipSuccess, r;
+#define EV_MX_ATTR(E) r = hipFuncSetAttribute((const void*)conv_gemm_mx_kernel<TAPS, (E)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    EV_MX_ATTR(EPI_O32) EV_MX_ATTR(EPI_RARE_ACT | EPI_O32) EV_MX_ATTR(EPI_RES32 | EPI_O32 | EPI_LEAN)
+    EV_MX_ATTR(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN) EV_MX_ATTR(EPI_GENERIC)
+#undef EV_MX_ATTR
+    return e;
+}
+static hipError_t mx_set_attributes() {
+    hipError_t e = hipSuccess, r;
+    r = mx_attr_taps<3>(); if (r != hipSuccess) e = r;
+    r = mx_attr_taps<7>(); if (r != hipSuccess) e = r;
+    r = mx_attr_taps<11>(); if (r != hipSuccess) e = r;
+    return e;
+}
+
+// Which calls take the MX kernel is a function of the layer's shape only (never of M): an utterance gets the same arithmetic alone
+// and inside a batch.  Everything else of a DT_MX call runs as the split-precision (three fp16 MFMAs) kernel.
+static bool mx_eligible(const ConvGemmParams& p) {
+    return p.W_mx && p.mx_scratch && p.N % 128 == 0 && p.K % 128 == 0 && (p.taps == 3 || p.taps == 7 || p.taps == 11) && p.M % PH_BM == 0 &&
+           p.lda == p.K && (p.taps - 1) * p.dil <= MAX_SPAN && p.mx_scratch_size >= mx_scratch_bytes(p.M, p.K);
+}
+static void launch_mx(const ConvGemmParams& p_in, hipStream_t s) {
+    ConvGemmParams p = p_in;
+    const MxPlaneLayout L = mx_layout(p.M, p.K);
+    char* const base = reinterpret_cast<char*>(p.mx_scratch);
+    const size_t r0 = MX_SLACK;
+    __half* H = reinterpret_cast<__half*>(base + L.h + r0 * p.K * 2);
+    uint8_t* x4h = reinterpret_cast<uint8_t*>(base + L.x4h + r0 * (p.K / 2));
+    uint8_t* x4l = reinterpret_cast<uint8_t*>(base + L.x4l + r0 * (p.K / 2));
+    uint8_t* sh = reinterpret_cast<uint8_t*>(base + L.sh + r0 * 4);
+    uint8_t* sl = reinterpret_cast<uint8_t*>(base + L.sl + r0 * 4);
+    const unsigned s_stride = (unsigned)(L.rows * 4);
+    const long threads = (long)p.M * (p.K / 8);
+    hipLaunchKernelGGL(mx_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(p.A), p.lda, p.M, p.K,
+                       p.pro_lrelu, p.pro_slope, H, x4h, x4l, sh, sl, s_stride);
+    p.A = H; p.lda = p.K; p.pro_lrelu = 0;
+    p.mx_x4[0] = x4h; p.mx_x4[1] = x4l; p.mx_xs[0] = sh; p.mx_xs[1] = sl; p.mx_xs_stride = s_stride;
+    switch (p.taps) {
+        case 3: launch_mx_taps<3>(p, s); break;
+        case 7: launch_mx_taps<7>(p, s); break;
+        default: launch_mx_taps<11>(p, s); break;
+    }
+}

@@ -8,7 +8,8 @@
 namespace ev {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LRELU = 3, ACT_TANH = 4 };
-enum DType { DT_F16 = 0, DT_F32 = 1, DT_F32S = 2 };   // F32S: fp32 activations, fp16 hi/lo split weights (ConvGemmParams::W / W_lo)
+enum DType { DT_F16 = 0, DT_F32 = 1, DT_F32S = 2, DT_MX = 3 };   // F32S: fp32 activations, fp16 hi/lo split weights (ConvGemmParams::W / W_lo)
+                                                                  // MX: fp32 activations; hi.hi as one fp16 MFMA + the two cross terms as block-scaled fp4 MFMAs (W, W_lo, W_mx)
 
 // out[m, n] = post( scale * ( act( sum_{tap,k} pro(A[m + (tap-center)*dil, k]) * W[n][tap][k] + bias[n] )
 //                              + seq_bias[row_seq[m]][n] + res[m, n] ) + acc32[m, n] + add16_a[m, n] + add16_b[m, n] )
@@ -37,7 +38,14 @@ struct ConvGemmParams {
     const void* add16_a; const void* add16_b; int ldadd;   // two fp16 tensors added after scaling (the MRF sum of three ResBlocks
                                                  // with the first two branches kept in fp16: half the traffic of acc32), or null
     int reserved1;
+    // DT_MX only.  W_mx: the weight's fp4 planes (emotivoice_amd/mxfp4.py: pack_weight_planes), null -> the call runs as DT_F32S.
+    // mx_scratch: device scratch for the activation planes of this call, >= mx_scratch_bytes(M, K) bytes (ev_gemm_mx.h).
+    const void* W_mx; void* mx_scratch; size_t mx_scratch_size;
+    // filled by the launcher (leave zero): fp4 code planes of the activations' hi / lo parts, their E8M0 scale planes
+    const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int reserved2;
 };
+// bytes of activation-plane scratch a DT_MX call with an [M][K] input needs
+size_t mx_scratch_bytes(int M, int K);
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
 // per-device setup of the kernels in ev_gemm.hip (large-LDS opt-in, CU count of the persistent kernels); 0 = OK
 int init_device_kernels(int device);

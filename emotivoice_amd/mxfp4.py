@@ -1,0 +1,105 @@
+"""OCP MX-fp4 (e2m1 elements, E8M0 power-of-two block scales) quantiser on the host, numpy only.
+
+Used by ``packer.py`` for the weight side of the "mx" precision mode and by the tests as the statement of what the device
+planes contain.  In that mode a product x.w (x = xh + xl, w = wh + wl, the fp16 hi parts and their fp32 remainders) is
+evaluated as
+
+    xh.wh                      one fp16 MFMA (v_mfma_f32_16x16x32_f16)
+  + Q(wl).Q(xh) + Q(wh).Q(xl)  two block-scaled fp4 MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4, 4x the fp16 rate)
+
+The cross terms are 2^-11 of the result, so the ~2 significant bits of fp4 leave a relative error of ~3e-5 per product instead
+of fp16's 3e-4 (tools/precision_study_mx.py: waveform 3.5e-4 against 2.3e-3 for plain fp16 operands, bar 1e-3).
+
+Element code (4 bits): s e e m, values +-{0, .5, 1, 1.5, 2, 3, 4, 6}; two codes per byte, element 2j in the low nibble of
+byte j (checked against the instruction on the device: tools/mfma_ubench.hip).  Scale byte b means 2^(b - 127); the block scale
+is 2^(floor(log2(amax)) - 2) (OCP MX v1.0: the largest element lands in the top binade, values above 6 saturate).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FP4_VALUES = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], np.float32)
+
+
+def scale_bytes(amax: np.ndarray) -> np.ndarray:
+    """E8M0 byte of the block scale for a block whose largest magnitude is ``amax`` (fp32): biased exponent - 2, at least 1
+    (0 would be 2^-127, a subnormal the conversion instruction cannot divide by; all-zero blocks get 1)."""
+    bits = np.ascontiguousarray(amax, np.float32).view(np.uint32)
+    e = ((bits >> 23) & 0xFF).astype(np.int32) - 2
+    return np.clip(e, 1, 254).astype(np.uint8)
+
+
+def encode_fp4(y: np.ndarray) -> np.ndarray:
+    """fp32 (already divided by the block scale) -> 4-bit codes, round to nearest even, saturating at 6."""
+    a = np.abs(y)
+    c = ((a > 0.25).astype(np.uint8) + (a >= 0.75) + (a > 1.25) + (a >= 1.75) + (a > 2.5) + (a >= 3.5) + (a > 5.0)).astype(np.uint8)
+    return (c | (np.signbit(y).astype(np.uint8) << 3)).astype(np.uint8)
+
+
+def decode_fp4(codes: np.ndarray) -> np.ndarray:
+    v = FP4_VALUES[codes & 7]
+    return np.where(codes & 8, -v, v).astype(np.float32)
+
+
+def quantize(v: np.ndarray, block: int = 32):
+    """v [..., K] fp32 (K % block == 0, block % 32 == 0) -> (codes uint8 [..., K/2], scales uint8 [..., K/block]).
+    One scale per ``block`` consecutive elements (the instruction takes one per 32; a coarser block repeats it)."""
+    v = np.ascontiguousarray(v, np.float32)
+    K = v.shape[-1]
+    assert K % block == 0 and block % 32 == 0
+    blk = v.reshape(v.shape[:-1] + (K // block, block))
+    sb = scale_bytes(np.abs(blk).max(-1))
+    inv = np.ldexp(np.float32(1.0), 127 - sb.astype(np.int32)).astype(np.float32)
+    codes = encode_fp4(blk * inv[..., None]).reshape(v.shape)
+    packed = (codes[..., 0::2] | (codes[..., 1::2] << 4)).astype(np.uint8)
+    return packed, sb
+
+
+def dequantize(packed: np.ndarray, sb: np.ndarray, block: int = 32) -> np.ndarray:
+    codes = np.empty(packed.shape[:-1] + (packed.shape[-1] * 2,), np.uint8)
+    codes[..., 0::2] = packed & 15
+    codes[..., 1::2] = packed >> 4
+    v = decode_fp4(codes)
+    K = v.shape[-1]
+    sc = np.ldexp(np.float32(1.0), sb.astype(np.int32) - 127).astype(np.float32)
+    return (v.reshape(v.shape[:-1] + (K // block, block)) * sc[..., None]).reshape(v.shape)
+
+
+def split_hi_lo(x: np.ndarray):
+    """fp32 -> (fp16 hi part as fp32, exact fp32 remainder)."""
+    x = np.ascontiguousarray(x, np.float32)
+    hi = x.astype(np.float16).astype(np.float32)
+    return hi, x - hi
+
+
+W_SCALE_BLOCK = 128     # weights: one scale per (output channel, tap, 128 input channels) = one per MFMA A-row
+
+
+def pack_weight_planes(w: np.ndarray) -> np.ndarray:
+    """GEMM-layout weight [N][taps][K] fp32 (N % 128 == 0, K % 128 == 0) -> one byte array
+         [wl4: N x taps x K/2] [wh4: N x taps x K/2] [swl: N/128 x K/128 x taps x 128] [swh: same]
+    wl4 / wh4: fp4 codes of the fp32 remainder w - fp16(w) and of fp16(w); scale planes are tile-major so that the scales of one
+    (128-channel output tile, 128-channel K chunk) are ``taps * 128`` contiguous bytes (one or two LDS-DMA pieces)."""
+    w = np.ascontiguousarray(w, np.float32)
+    N, taps, K = w.shape
+    assert N % 128 == 0 and K % 128 == 0, (N, K)
+    hi, lo = split_hi_lo(w)
+    out = []
+    scales = []
+    for part in (lo, hi):
+        codes, sb = quantize(part, W_SCALE_BLOCK)              # sb [N][taps][K/128]
+        out.append(codes.reshape(-1))
+        scales.append(np.ascontiguousarray(sb.reshape(N // 128, 128, taps, K // 128).transpose(0, 3, 2, 1)).reshape(-1))
+    return np.concatenate(out + scales)
+
+
+def weight_planes_dequant(blob: np.ndarray, N: int, taps: int, K: int):
+    """inverse of pack_weight_planes (tests): -> (Q(wl), Q(wh)) as fp32 [N][taps][K]."""
+    nc = N * taps * K // 2
+    ns = N * taps * (K // 128)
+    res = []
+    for i in range(2):
+        codes = blob[i * nc:(i + 1) * nc].reshape(N, taps, K // 2)
+        sb = blob[2 * nc + i * ns: 2 * nc + (i + 1) * ns].reshape(N // 128, K // 128, taps, 128).transpose(0, 3, 2, 1).reshape(N, taps, K // 128)
+        res.append(dequantize(codes, sb, W_SCALE_BLOCK))
+    return res[0], res[1]

@@ -20,7 +20,9 @@ extern "C" {
  * Field order and types mirror ev::ConvGemmParams exactly. */
 typedef struct ev_conv_gemm_desc {
     int dtype;                 /* 0: fp16 operands (MFMA 16x16x32 f16), 1: fp32 operands (MFMA 16x16x4 f32),
-                                  2: fp32 activations x fp16 hi/lo split weights, 3 fp16 MFMAs per product (fp32-level accuracy) */
+                                  2: fp32 activations x fp16 hi/lo split weights, 3 fp16 MFMAs per product (fp32-level accuracy),
+                                  3: fp32 activations; hi x hi as one fp16 MFMA + the two cross terms as block-scaled fp4 MFMAs
+                                     (v_mfma_scale_f32_16x16x128_f8f6f4): needs W, W_lo, W_mx, mx_scratch */
     const void* A; int lda;
     const void* W;
     const void* W_lo;          /* dtype 2 only */
@@ -39,9 +41,14 @@ typedef struct ev_conv_gemm_desc {
     int reserved0;
     const void* add16_a; const void* add16_b; int ldadd;   /* two fp16 [M][N] tensors added after scaling (both or neither), or NULL */
     int reserved1;
+    const void* W_mx;          /* dtype 3: emotivoice_amd/mxfp4.py pack_weight_planes(W) on the device (NULL: the call runs as dtype 2) */
+    void* mx_scratch; size_t mx_scratch_size;   /* dtype 3: device scratch, >= ev_op_mx_scratch_bytes(M, K) */
+    const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int reserved2;   /* launcher-internal: leave zero */
 } ev_conv_gemm_desc;
 
 int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* hip_stream);
+/* scratch bytes a dtype-3 call with an [M][K] activation needs (fp16 hi plane, two fp4 code planes, two E8M0 scale planes) */
+size_t ev_op_mx_scratch_bytes(int M, int K);
 
 /* Fused HiFi-GAN ResBlock1 pair for C = 32: xt = lrelu(c1(lrelu(x)) + b1); out = epi(c2(xt) + b2 + x)
  * (reference models/hifigan/models.py:50-57).  `epi` uses the ev_conv_gemm_desc fields bias (= b2), res (= x), res_dtype,

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""CPU emulation of "one fp16 MFMA + block-scaled (MX) cross terms" recipes for the HiFi-GAN generator (tuning tool).
+
+A product x.w with x = xh + xl, w = wh + wl (xh = fp16(x), xl = x - xh) needs xh.wh + xh.wl + xl.wh for fp32-class
+accuracy (the "strict" mode: three fp16 MFMAs).  The two cross terms are 2^-11 of the result, so a few significant bits are
+enough for the 1e-3 contract: this tool evaluates them in the OCP MX formats of `v_mfma_scale_f32_16x16x128_f8f6f4`
+(fp4 e2m1 / fp6 e2m3 at 4x the fp16 MFMA rate, fp8 e4m3 at 2x), with one E8M0 scale per 32 consecutive K elements
+(= 32 input channels of one tap), and reports the waveform error on the zero-mean reference fixture recipe.
+
+    python tools/precision_study_mx.py [--phonemes 48]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import EVShapes, am_forward, hifigan_forward, synth_inputs, synth_state_dict  # noqa: E402
+from oracle.jets_oracle import fold_weight_norm, to_torch_sd  # noqa: E402
+
+FORMATS = {            # ebits, mbits, emax (unbiased exponent of the largest binade), max value
+    "fp4": (2, 1, 2, 6.0),
+    "fp6": (2, 3, 2, 7.5),
+    "fp8": (4, 3, 8, 448.0),
+}
+
+
+def r16(x):
+    return x.half().float()
+
+
+def quant_elem(v, fmt):
+    """round-to-nearest-even of v into a small float format (no block scale), saturating."""
+    ebits, mbits, emax, vmax = FORMATS[fmt]
+    emin = 2 - (1 << (ebits - 1))          # smallest normal exponent (bias = 2^(ebits-1) - 1)
+    a = v.abs().clamp_min(1e-38)
+    e = torch.floor(torch.log2(a)).clamp(emin, emax)
+    quantum = torch.exp2(e - mbits)
+    out = torch.round(v / quantum) * quantum
+    return out.clamp(-vmax, vmax)
+
+
+def mx_quant(v, fmt, dim):
+    """MX block quantisation along `dim` in blocks of 32 (zero padded): shared power-of-two scale from the block max
+    (OCP MX: scale = 2^(floor(log2(amax)) - emax_elem))."""
+    if fmt is None:
+        return v
+    v = v.movedim(dim, -1)
+    n = v.shape[-1]
+    pad = (-n) % 32
+    vp = F.pad(v, (0, pad))
+    blk = vp.reshape(*vp.shape[:-1], -1, 32)
+    amax = blk.abs().amax(-1, keepdim=True)
+    emax = FORMATS[fmt][2]
+    scale = torch.exp2(torch.floor(torch.log2(amax.clamp_min(1e-38))) - emax)
+    scale = torch.where(amax > 0, scale, torch.ones_like(scale))
+    qv = quant_elem(blk / scale, fmt) * scale
+    return qv.reshape(vp.shape)[..., :n].movedim(-1, dim)
+
+
+class Recipe:
+    def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh")):
+        self.name, self.cross, self.res32, self.op32, self.lo_terms = name, cross, res32, op32, lo_terms
+
+
+def conv_mx(x, w, b, rc, transposed=False, **kw):
+    """x [1, C, T] fp32, w fp32.  hi.hi in fp16 operands + cross terms in rc.cross (None = omitted, 'f16' = fp16 exact)."""
+    op = F.conv_transpose1d if transposed else F.conv1d
+    xh, wh = r16(x), r16(w)
+    y = op(xh, wh, b, **kw)
+    if rc.cross is None:
+        return y
+    xl, wl = x - xh, w - wh
+    kdim_w = 0 if transposed else 1      # conv_transpose weight is [Cin, Cout, k]
+    if rc.cross == "f16":
+        qa = qb = lambda t, d: r16(t)
+    else:
+        qa = qb = lambda t, d: mx_quant(t, rc.cross, d)
+    if "xh_wl" in rc.lo_terms:
+        y = y + op(qa(xh, 1), qb(wl, kdim_w), None, **kw)
+    if "xl_wh" in rc.lo_terms:
+        y = y + op(qa(xl, 1), qb(wh, kdim_w), None, **kw)
+    return y
+
+
+def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
+    st = (lambda t: t) if rc.res32 else r16              # residual-stream / stage tensors
+    so = (lambda t: t) if rc.op32 else r16               # conv1 -> conv2 intermediates (operand-only tensors)
+
+    def conv(x, name, **kw):
+        return conv_mx(x, fold_weight_norm(sd, name), sd[name + ".bias"], rc, **kw)
+
+    x = mel_ct.unsqueeze(0)
+    x = st(conv(x, prefix + ".conv_pre", padding=3))
+    nk = len(shapes.rb_kernels)
+    for i, (u, k) in enumerate(zip(shapes.up_rates, shapes.up_kernels)):
+        x = F.leaky_relu(x, 0.1)
+        x = conv_mx(x, fold_weight_norm(sd, f"{prefix}.ups.{i}"), sd[f"{prefix}.ups.{i}.bias"], rc, transposed=True,
+                    stride=u, padding=(k - u) // 2)
+        x = st(x)
+        xs = None
+        for j, (rk, dils) in enumerate(zip(shapes.rb_kernels, shapes.rb_dils)):
+            r = f"{prefix}.resblocks.{i * nk + j}"
+            y = x
+            for d_i, d in enumerate(dils):
+                xt = conv(F.leaky_relu(y, 0.1), f"{r}.convs1.{d_i}", dilation=d, padding=(rk * d - d) // 2)
+                xt = so(F.leaky_relu(xt, 0.1))
+                xt = conv(xt, f"{r}.convs2.{d_i}", dilation=1, padding=(rk - 1) // 2)
+                y = st(xt + y)
+            y = y / nk
+            xs = y if xs is None else xs + y
+        x = st(xs)
+    x = F.leaky_relu(x)
+    x = F.conv1d(x, fold_weight_norm(sd, prefix + ".conv_post"), sd[prefix + ".conv_post.bias"], padding=3)
+    return torch.tanh(x).view(-1)
+
+
+def errs(a, b):
+    a, b = a.double().numpy(), b.double().numpy()
+    d = np.linalg.norm(a - b)
+    return d / np.linalg.norm(b), d / np.linalg.norm(b - b.mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--phonemes", type=int, default=48)
+    ap.add_argument("--seed", type=int, default=21)
+    ap.add_argument("--mel16", action="store_true", help="round the generator's mel input to fp16 first")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    shapes = EVShapes()
+    sd = to_torch_sd(synth_state_dict(0, "parity"))
+    utt = synth_inputs(args.seed, [args.phonemes], [7])[0]
+    with torch.no_grad():
+        am = am_forward(sd, torch.from_numpy(utt["ling"]), 7, torch.from_numpy(utt["style"]), torch.from_numpy(utt["content"]), shapes)
+        mel = am["dec_outputs"].t().contiguous()
+        lo, hi = -20.0, 20.0
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            sd["generator.conv_post.bias"] = torch.tensor([mid])
+            if hifigan_forward(sd, mel, shapes).mean().item() > 0:
+                hi = mid
+            else:
+                lo = mid
+        ref = hifigan_forward(sd, mel, shapes)
+        print("frames %d  wav mean %.4f  std %.4f" % (mel.shape[1], ref.mean().item(), ref.std().item()))
+        cases = [
+            Recipe("hi.hi only, fp32 storage (1 MFMA)", None),
+            Recipe("hi.hi only, fp16 storage (= fast)", None, res32=False, op32=False),
+            Recipe("+ fp16 cross terms, fp32 storage (= strict)", "f16"),
+            Recipe("+ fp16 cross terms, fp16 residual stream", "f16", res32=False),
+            Recipe("+ MX-fp8 cross terms, fp32 storage", "fp8"),
+            Recipe("+ MX-fp6 cross terms, fp32 storage", "fp6"),
+            Recipe("+ MX-fp4 cross terms, fp32 storage", "fp4"),
+            Recipe("+ MX-fp4 cross terms, fp16 residual stream", "fp4", res32=False),
+            Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
+            Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
+        ]
+        m_in = r16(mel) if args.mel16 else mel
+        for rc in cases:
+            out = emulate(sd, m_in, shapes, rc)
+            e, eac = errs(out, ref)
+            print("%-52s wav %.3e   wav_ac %.3e" % (rc.name, e, eac), flush=True)
+
+
+if __name__ == "__main__":
+    main()
