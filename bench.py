@@ -2,7 +2,8 @@
 """Throughput of the EmotiVoice hot path (JETSGenerator.forward = acoustic model + HiFi-GAN) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--mode am_vocoder|ragged|vocoder] [--precision fast|strict]
-                                                   (N > 1: launched by torch.distributed.run, one rank per GPU)
+        N > 1: one rank per GPU.  Started by a launcher (torch.distributed.run: WORLD_SIZE set) it is a rank and requires
+        WORLD_SIZE == N; started bare it becomes the launcher itself (spawn_command) -- `python bench.py --gpus 8` runs 8 ranks.
 
 Workloads (BASELINE.json configs; seeded synthetic weights and inputs, nothing is read from disk):
   am_vocoder (default) -- configs[1]: batch 32 x 256 synthetic phonemes, one speaker, AM + vocoder end to end; the duration head
@@ -21,6 +22,7 @@ timed as well and reported under "other_precision".  Prints ONE JSON line on ran
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -251,6 +253,39 @@ def bench_style(args, torch):
     print(json.dumps(line))
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_command(n, argv):
+    """The launcher command `python bench.py --gpus N ...` turns into when no launcher started it: torch.distributed.run with
+    one rank per GPU on this node, rendezvous on 127.0.0.1 (the reference's analogue is the process-per-GPU fan-out of
+    inference_tts.py:178-220)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def rendezvous_only(rank, world):
+    """Launch check without a GPU: every rank joins the group, rank 0 prints what the real run would print about the job's shape."""
+    import torch
+    ranks_seen = [0]
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rk = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(rk, torch.tensor([rank], dtype=torch.int64))
+        ranks_seen = [int(t.item()) for t in rk]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_seen": ranks_seen}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,14 +303,26 @@ def main():
     ap.add_argument("--no-other-precision", action="store_true", help="skip the extra timed pass in the other precision (N = 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: put every rank on this device (with --backend gloo)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch check: the ranks meet (gloo), rank 0 prints n_gpus / ranks_seen, nothing touches a GPU")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher of N ranks (one per GPU) running this same command line
+        raise SystemExit(subprocess.call(spawn_command(args.gpus, sys.argv[1:])))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.rendezvous_only:
+        return rendezvous_only(rank, world)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: emotivoice_amd has no CPU fallback")
+    if args.force_device < 0 and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
     if args.force_device >= 0:
         local_rank = args.force_device
     if args.sub_batches <= 0:

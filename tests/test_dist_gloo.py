@@ -45,3 +45,40 @@ def test_broadcast_and_shard_world2(tmp_path):
     assert recs[0][2] == recs[0][3] == recs[1][2]          # all_reduce of the per-rank frame counters == total
     a, b = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     assert sorted(a.tolist() + b.tolist()) == list(range(37)) and not set(a) & set(b)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(argv, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must BE the launcher: two ranks meet and rank 0 reports n_gpus = 2
+    (round 2's bench parsed --gpus and ran one process).  --rendezvous-only stops after the process group: no GPU here."""
+    r, line = _run_bench(["--gpus", "2", "--rendezvous-only"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert line == {"rendezvous_only": True, "n_gpus": 2, "ranks_seen": [0, 1]}
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r, line = _run_bench(["--gpus", "2", "--rendezvous-only"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and line is None and "WORLD_SIZE=3" in r.stderr
+    r, line = _run_bench(["--gpus", "1", "--rendezvous-only"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and line is None
+
+
+def test_bench_spawn_command_shape():
+    import bench
+    cmd = bench.spawn_command(4, ["--gpus", "4", "--steps", "3"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert os.path.basename(cmd[-5]) == "bench.py"

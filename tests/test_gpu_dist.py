@@ -36,3 +36,21 @@ def test_two_ranks_reproduce_single_process(tmp_path):
         for i in p["idx"]:
             assert np.array_equal(p["wav%d" % int(i)], ref["wav_list"][int(i)]), int(i)
     eng.close()
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` (no launcher) on the one-GPU box: both ranks on device 0 over gloo; the line must say n_gpus 2,
+    both ranks seen, and twice the frames of one rank's batch."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--force-device", "0", "--batch", "4", "--sub-batches", "1", "--phonemes", "64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["config"]["global_batch"] == 8
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 4 * 64 * 4) < 1.0       # frames per step over both ranks
