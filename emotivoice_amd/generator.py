@@ -171,9 +171,12 @@ class JETSGeneratorHIP:
 
     def _forward_device(self, eng, inputs_ling, input_lengths, inputs_speaker, inputs_style_embedding, inputs_content_embedding):
         """The reference's own call pattern (inference_am_vocoder_joint.py:115-129): every input already a CUDA tensor.  Nothing
-        is staged through the host: the engine runs on torch's CURRENT stream (ev_set_stream) and reads the tensors in place
-        (EV_FLAG_DEVICE_INPUTS); the outputs are cloned on the same stream, so ordering against later torch work is the
-        stream's.  One small device -> host copy remains, the lengths (the reference synchronises too, alignment.py:195).
+        is staged through the host: the engine reads the tensors in place (EV_FLAG_DEVICE_INPUTS) and, when torch's current stream
+        is a real stream, runs ON it (ev_set_stream), the outputs are cloned on the same stream, and ordering against later torch
+        work is the stream's.  When the current stream is the DEFAULT stream (handle 0, which ev_set_stream maps to the engine's own
+        non-blocking stream: no implicit ordering against the null stream), the call is fenced by hand instead: the input
+        preparation is finished before the engine starts, and the output clones before the arena can be reused.  One small
+        device -> host copy remains, the lengths (the reference synchronises too, alignment.py:195).
         Ids are not range-checked on this path (that would be a second sync): the kernels clamp them to the tables."""
         import torch
         dev = inputs_ling.device
@@ -201,11 +204,16 @@ class JETSGeneratorHIP:
         content = as_dev(inputs_content_embedding, torch.float32).reshape(B, -1).contiguous()
         cu = np.zeros(B + 1, np.int32)
         cu[1:] = np.cumsum(lengths)
+        fenced = stream.cuda_stream == 0
+        if fenced:
+            stream.synchronize()            # the cat / casts above were queued on the null stream; the engine's stream does not wait for it
         res = eng.synthesize_raw(B, packed.data_ptr(), cu, spk.data_ptr(), style.data_ptr(), content.data_ptr(), 1.0,
                                  _ffi.EV_FLAG_DEVICE_INPUTS)
         T = np.array([res.mel_lens[b] for b in range(B)], np.int64)
         offs = np.array([res.mel_offsets[b] for b in range(B + 1)], np.int64)
         out = self._gather_torch(eng, res, B, Nmax, lengths, cu, T, offs, self.upsample_factor)
+        if fenced:
+            stream.synchronize()            # the clones read the handle's arena, which the next call overwrites
         out.update(mel_targets=None, postnet_outputs=None, pitch_targets=None, energy_targets=None, duration_targets=None,
                    input_lengths=input_lengths, output_lengths=None, log_p_attn=None, bin_loss=None, z_start_idxs=None,
                    segment_size=self.segment_size)

@@ -122,12 +122,19 @@ def run_chunk(lines: Sequence[str], start_idx: int, chunk_num: int, *, synthesiz
         if not utts:
             continue
         try:
-            out = synthesize(utts)
-        except Exception as e:                                                    # noqa: BLE001 -- a failing batch loses its lines, not the run
-            log("Error: %s" % (e,))
-            stats["errors"] += len(utts)
-            continue
-        for (content, wav_path, txt_path), wav in zip(keep, out["wav_list"]):
+            wavs = list(synthesize(utts)["wav_list"])
+        except Exception:                                                         # noqa: BLE001 -- re-run the batch a line at a time: only the
+            wavs = []                                                             # offending line is lost, as in the reference (:154-156)
+            for u in utts:
+                try:
+                    wavs.append(synthesize([u])["wav_list"][0])
+                except Exception as e:                                            # noqa: BLE001
+                    log("Error: %s" % (e,))
+                    stats["errors"] += 1
+                    wavs.append(None)
+        for (content, wav_path, txt_path), wav in zip(keep, wavs):
+            if wav is None:
+                continue
             write_wav_int16(wav_path, wav_float_to_int16(wav), sampling_rate)     # :145-150
             with open(txt_path, "w", encoding="utf-8") as f:                      # :151-153
                 f.write("%s\n" % content)
@@ -149,6 +156,13 @@ def main_worker(args, config, gpu_id: int, start_idx: int, chunk_num: int, state
     output_dir = args.output_dir or os.path.join(root_path, "audio")              # :53-57
     os.makedirs(output_dir, exist_ok=True)
     conf = load_yaml(config.model_config_path, n_vocab=config.n_symbols, n_speaker=config.speaker_n_labels)     # :59-63
+    # the G2P worker pool forks its workers in its constructor: it must exist BEFORE this process initialises the HIP runtime
+    # (.to("cuda:N") below) -- a forked child of an initialised parent inherits runtime threads, locks and KFD state
+    g2p = (lambda s: s) if args.phoneme_input else load_g2p(args.g2p)
+    pool = None
+    if args.frontend_workers > 1 and not args.phoneme_input:
+        from .frontend_pool import FrontendPool
+        pool = FrontendPool(g2p, workers=args.frontend_workers)
     gen = JETSGeneratorHIP(conf, precision=args.precision)
     if state_dict is None:
         if args.synthetic_weights:
@@ -166,11 +180,6 @@ def main_worker(args, config, gpu_id: int, start_idx: int, chunk_num: int, state
     embed = _device_style_embedder(config, gen) or HashStyleEmbedder(gen.shapes.bert_dim)
     with open(args.text_file, "r", encoding="utf-8") as f:
         lines = f.readlines()
-    g2p = (lambda s: s) if args.phoneme_input else load_g2p(args.g2p)
-    pool = None
-    if args.frontend_workers > 1 and not args.phoneme_input:
-        from .frontend_pool import FrontendPool
-        pool = FrontendPool(g2p, workers=args.frontend_workers)
     eng = gen._ensure_engine()
     try:
         stats = run_chunk(lines, start_idx, chunk_num, synthesize=eng.synthesize, embed=embed, g2p=g2p, token2id=token2id,

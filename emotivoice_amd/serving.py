@@ -32,8 +32,8 @@ from .text_io import wav_float_to_int16
 class SynthesisRequest:
     ling: np.ndarray                 # (N,) int64 phoneme ids
     speaker: int
-    style: np.ndarray                # (768,)
-    content: np.ndarray              # (768,)
+    style: object                    # (768,) array, or the prompt TEXT when the batcher owns the embedder (embed_batch_fn)
+    content: object                  # (768,) array, or the content text
     alpha: float = 1.0               # duration scale (1 / speed)
     future: Future = field(default_factory=Future)
     t_submit: float = field(default_factory=time.perf_counter)
@@ -41,29 +41,74 @@ class SynthesisRequest:
 
 class DynamicBatcher:
     """Collects requests into batches for ``synth_fn(utts, alpha) -> list of float waveforms`` (one per utterance, in order).
-    One worker thread owns the engine handle (the handle is not thread-safe, include/evhip.h)."""
+    One worker thread owns the engine handle (the handle is not thread-safe, include/evhip.h): everything that touches the
+    handle runs on that thread -- including the style / content embedding when the embedder lives on the same handle
+    (``embed_batch_fn(texts) -> (len(texts), 768)``: requests then carry the TEXTS and the worker embeds a whole batch at once,
+    which also batches the BERT forward)."""
 
     def __init__(self, synth_fn: Callable[[List[dict], float], Sequence[np.ndarray]], max_batch: int = 32, max_wait_ms: float = 5.0,
-                 max_tokens: int = 16384):
+                 max_tokens: int = 16384, embed_batch_fn: Optional[Callable[[List[str]], np.ndarray]] = None,
+                 n_vocab: Optional[int] = None, n_speaker: Optional[int] = None, max_len: int = 4096):
         self.synth_fn, self.max_batch, self.max_wait, self.max_tokens = synth_fn, max_batch, max_wait_ms * 1e-3, max_tokens
+        self.embed_batch_fn, self.n_vocab, self.n_speaker, self.max_len = embed_batch_fn, n_vocab, n_speaker, max_len
         self._q: "queue.Queue[Optional[SynthesisRequest]]" = queue.Queue()
         self._carry: List[SynthesisRequest] = []
         self.batches: List[int] = []          # sizes of the batches formed so far (observability / tests)
+        self.retried: int = 0                 # batches that failed as a whole and were re-run one request at a time
         self._stop = False
+        self._lock = threading.Lock()         # orders submit's (closed? -> enqueue) against close's (closed := True -> sentinel)
         self._thread = threading.Thread(target=self._loop, name="ev-batcher", daemon=True)
         self._thread.start()
 
     def submit(self, ling, speaker: int, style, content, alpha: float = 1.0) -> Future:
-        if self._stop:
-            raise RuntimeError("batcher is closed")
-        req = SynthesisRequest(np.asarray(ling, np.int64), int(speaker), np.asarray(style, np.float32), np.asarray(content, np.float32), float(alpha))
-        self._q.put(req)
+        """Validation happens HERE (ValueError -> the handler's 400), so that one malformed request cannot take the requests
+        batched with it down: the reference serves every request on its own (openaiapi.py:159-184)."""
+        ling = np.asarray(ling, np.int64).reshape(-1)
+        if ling.size == 0:
+            raise ValueError("empty phoneme sequence")
+        if ling.size > self.max_len:
+            raise ValueError("phoneme sequence too long (%d > %d)" % (ling.size, self.max_len))
+        if ling.min() < 0 or (self.n_vocab is not None and ling.max() >= self.n_vocab):
+            raise ValueError("phoneme id out of range")
+        if int(speaker) < 0 or (self.n_speaker is not None and int(speaker) >= self.n_speaker):
+            raise ValueError("speaker id out of range")
+        if not (alpha > 0 and np.isfinite(alpha)):
+            raise ValueError("alpha must be positive")
+
+        def emb(x):
+            if isinstance(x, str):
+                if self.embed_batch_fn is None:
+                    raise ValueError("text embeddings need a batcher with embed_batch_fn")
+                return x
+            x = np.asarray(x, np.float32).reshape(-1)
+            if not np.isfinite(x).all():
+                raise ValueError("embedding is not finite")
+            return x
+        req = SynthesisRequest(ling, int(speaker), emb(style), emb(content), float(alpha))
+        with self._lock:
+            if self._stop:
+                raise RuntimeError("batcher is closed")
+            self._q.put(req)
         return req.future
 
-    def close(self):
-        self._stop = True
-        self._q.put(None)
-        self._thread.join(timeout=30)
+    def close(self, timeout: float = 30.0):
+        with self._lock:
+            if not self._stop:
+                self._stop = True
+                self._q.put(None)
+        self._thread.join(timeout=timeout)
+        # whatever is still queued or carried (worker timed out, or died) must not leave its client waiting
+        left = list(self._carry) if not self._thread.is_alive() else []
+        while True:
+            try:
+                r = self._q.get_nowait()
+            except queue.Empty:
+                break
+            if r is not None:
+                left.append(r)
+        for r in left:
+            if not r.future.done():
+                r.future.set_exception(RuntimeError("batcher closed"))
 
     def _take_batch(self) -> List[SynthesisRequest]:
         """Block for the first request, then keep collecting until the batch is full, the token budget is reached or
@@ -97,6 +142,23 @@ class DynamicBatcher:
                 self._carry.append(r)
         return batch
 
+    def _run(self, batch: List[SynthesisRequest]):
+        if self.embed_batch_fn is not None:
+            texts = sorted({x for r in batch for x in (r.style, r.content) if isinstance(x, str)})
+            if texts:
+                vec = np.asarray(self.embed_batch_fn(texts), np.float32)
+                if vec.shape[0] != len(texts):
+                    raise RuntimeError("embed_batch_fn returned %d vectors for %d texts" % (vec.shape[0], len(texts)))
+                table = {t: vec[i] for i, t in enumerate(texts)}
+                for r in batch:
+                    r.style = table[r.style] if isinstance(r.style, str) else r.style
+                    r.content = table[r.content] if isinstance(r.content, str) else r.content
+        wavs = self.synth_fn([dict(ling=r.ling, speaker=r.speaker, style=r.style, content=r.content) for r in batch], batch[0].alpha)
+        if len(wavs) != len(batch):
+            raise RuntimeError("synth_fn returned %d waveforms for %d requests" % (len(wavs), len(batch)))
+        for r, w in zip(batch, wavs):
+            r.future.set_result(np.array(w, np.float32, copy=True))
+
     def _loop(self):
         while True:
             batch = self._take_batch()
@@ -106,20 +168,32 @@ class DynamicBatcher:
                 continue
             self.batches.append(len(batch))
             try:
-                wavs = self.synth_fn([dict(ling=r.ling, speaker=r.speaker, style=r.style, content=r.content) for r in batch], batch[0].alpha)
-                if len(wavs) != len(batch):
-                    raise RuntimeError("synth_fn returned %d waveforms for %d requests" % (len(wavs), len(batch)))
-                for r, w in zip(batch, wavs):
-                    r.future.set_result(np.array(w, np.float32, copy=True))
-            except Exception as e:          # the whole batch fails together; other batches are unaffected
+                self._run(batch)
+            except Exception as e:
+                if len(batch) == 1:
+                    batch[0].future.set_exception(e)
+                    continue
+                # a batch failed as a whole: re-run its requests one at a time so that only the offender fails
+                self.retried += 1
                 for r in batch:
-                    if not r.future.done():
-                        r.future.set_exception(e)
+                    if r.future.done():
+                        continue
+                    try:
+                        self._run([r])
+                    except Exception as e1:
+                        r.future.set_exception(e1)
 
 
 def engine_synth_fn(engine) -> Callable[[List[dict], float], Sequence[np.ndarray]]:
     """``synth_fn`` of a DynamicBatcher for an EVEngine."""
     return lambda utts, alpha: engine.synthesize(utts, alpha=alpha)["wav_list"]
+
+
+def engine_embed_batch_fn(engine, tokenize: Callable[[str], Sequence[int]]) -> Callable[[List[str]], np.ndarray]:
+    """``embed_batch_fn`` of a DynamicBatcher for the device SimBERT living on ``engine`` (ev_style_embed on the SAME handle as
+    ev_synthesize -- which is why it has to run on the batcher's thread): ``tokenize(text) -> [CLS] ... [SEP]`` ids
+    (emotivoice_amd.wordpiece or the reference's AutoTokenizer, simbert.py / inference_am_vocoder_joint.py:25-38)."""
+    return lambda texts: engine.style_embed([np.asarray(tokenize(t), np.int64) for t in texts])
 
 
 def encode_audio(wav_f32: np.ndarray, response_format: str, sample_rate: int) -> bytes:
@@ -141,13 +215,22 @@ class TTSService:
     through a tokenizer, or a placeholder)."""
 
     def __init__(self, batcher: DynamicBatcher, token2id: Dict[str, int], speaker2id: Dict[str, int], g2p: Callable[[str], str],
-                 embed: Callable[[str], np.ndarray], sample_rate: int = 16000):
+                 embed: Optional[Callable[[str], np.ndarray]] = None, sample_rate: int = 16000):
+        """``embed`` runs on the CALLER's thread (FastAPI's handler pool): it must be thread-safe and must not share an engine
+        handle with the batcher.  For the device SimBERT on the generator's own handle leave it None and give the BATCHER an
+        ``embed_batch_fn``: the texts then travel with the request and are embedded on the worker thread, a batch at a time."""
         self.batcher, self.token2id, self.speaker2id, self.g2p, self.embed, self.sample_rate = batcher, token2id, speaker2id, g2p, embed, sample_rate
+        if embed is None and batcher.embed_batch_fn is None:
+            raise ValueError("TTSService needs embed= or a batcher with embed_batch_fn=")
 
     def submit(self, text: str, voice: str, prompt: str = "", speed: float = 1.0) -> Future:
         if not (0.25 <= speed <= 4.0):
             raise ValueError("speed must be within [0.25, 4]")
         ling = np.array([self.token2id[ph] for ph in self.g2p(text).split()], np.int64)       # KeyError like openaiapi.py:128
+        if ling.size == 0:
+            raise ValueError("input has no phonemes")
+        if self.embed is None:
+            return self.batcher.submit(ling, self.speaker2id[voice], prompt, text, alpha=1.0 / speed)
         return self.batcher.submit(ling, self.speaker2id[voice], self.embed(prompt), self.embed(text), alpha=1.0 / speed)
 
     def speech(self, text: str, voice: str, prompt: str = "", speed: float = 1.0, response_format: str = "wav", timeout: float = 120.0) -> bytes:

@@ -92,6 +92,22 @@ def test_run_chunk_failing_batch_does_not_stop_the_run(tmp_path):
     assert stats == dict(written=2, skipped_existing=0, errors=1)
 
 
+def test_run_chunk_bad_line_costs_one_line_not_its_batch(tmp_path):
+    """with --batch 3 a line the engine rejects used to drop all three; the batch is re-run line by line."""
+    calls = []
+
+    def synth(utts):
+        calls.append(len(utts))
+        if any(len(u["ling"]) == 2 for u in utts):
+            raise RuntimeError("device said no")
+        return dict(wav_list=[np.zeros(4, np.float32) for _ in utts])
+    stats = run_chunk(["a\n", "a a\n", "a a a\n"], 0, 3, synthesize=synth, embed=_embed, g2p=lambda s: s, token2id={"a": 0},
+                      id2speaker={0: "s"}, output_dir=str(tmp_path), sampling_rate=16000, batch=3, log=lambda m: None)
+    assert stats == dict(written=2, skipped_existing=0, errors=1) and calls == [3, 1, 1, 1]
+    assert os.path.exists(utt_paths(str(tmp_path), "s", 0)[1]) and os.path.exists(utt_paths(str(tmp_path), "s", 2)[1])
+    assert not os.path.exists(utt_paths(str(tmp_path), "s", 1)[1])
+
+
 def test_g2p_map_is_used_when_given(tmp_path):
     token2id, id2speaker = {"x": 0, "y": 1}, {0: "s"}
     eng = _StubEngine()

@@ -61,6 +61,88 @@ def test_batcher_failure_is_confined_to_its_batch():
         b.submit(np.arange(3), 1, np.zeros(768), np.zeros(768))
 
 
+def test_one_bad_request_does_not_fail_its_batch_mates():
+    """a request the engine rejects must not 500 the unrelated requests batched with it -- the batch is re-run one
+    request at a time and only the offender fails (the reference serves each request on its own)."""
+    calls = []
+
+    def fn(utts, alpha):
+        calls.append(len(utts))
+        if any(u["speaker"] == 13 for u in utts):
+            raise RuntimeError("boom")
+        return [np.full(4, u["speaker"], np.float32) for u in utts]
+
+    b = DynamicBatcher(fn, max_batch=8, max_wait_ms=200)
+    futs = [b.submit(np.arange(3), spk, np.zeros(768), np.zeros(768)) for spk in (1, 13, 2, 3)]
+    assert [f.result(timeout=5)[0] for i, f in enumerate(futs) if i != 1] == [1.0, 2.0, 3.0]
+    with pytest.raises(RuntimeError):
+        futs[1].result(timeout=5)
+    assert calls[0] == 4 and calls[1:] == [1, 1, 1, 1] and b.retried == 1
+    b.close()
+
+
+def test_submit_validates_before_batching():
+    b = DynamicBatcher(lambda u, a: [np.zeros(4, np.float32) for _ in u], max_batch=4, max_wait_ms=1, n_vocab=10, n_speaker=5, max_len=8)
+    z = np.zeros(768)
+    for ling, spk in (([], 0), ([1, 2, 10], 0), ([-1], 0), ([1, 2], 5), ([1, 2], -1), (list(range(9)), 0)):
+        with pytest.raises(ValueError):
+            b.submit(np.array(ling, np.int64), spk, z, z)
+    with pytest.raises(ValueError):
+        b.submit(np.arange(3), 0, np.full(768, np.nan), z)
+    with pytest.raises(ValueError):
+        b.submit(np.arange(3), 0, "a prompt text", z)               # texts need embed_batch_fn
+    assert b.submit(np.arange(3), 0, z, z).result(timeout=5).shape == (4,) and b.batches == [1]
+    b.close()
+
+
+def test_texts_are_embedded_on_the_worker_thread_one_call_per_batch():
+    """the device SimBERT shares the engine handle with ev_synthesize, so embedding must not run on the callers'
+    threads.  With embed_batch_fn the requests carry the texts; the worker embeds the batch's distinct texts in ONE call."""
+    import threading
+    seen = []
+
+    def embed_batch(texts):
+        seen.append((threading.current_thread().name, list(texts)))
+        return np.stack([np.full(768, len(t), np.float32) for t in texts])
+
+    got = []
+
+    def fn(utts, alpha):
+        got.append([(float(u["style"][0]), float(u["content"][0])) for u in utts])
+        return [np.zeros(4, np.float32) for _ in utts]
+
+    b = DynamicBatcher(fn, max_batch=8, max_wait_ms=200, embed_batch_fn=embed_batch)
+    svc = TTSService(b, {"a": 1}, {"v": 0}, g2p=lambda t: "a " * len(t))
+    futs = [svc.submit(t, "v", prompt="happy") for t in ("xx", "yyy", "xx")]
+    [f.result(timeout=5) for f in futs]
+    b.close()
+    assert len(seen) == 1 and seen[0][0] == "ev-batcher" and seen[0][1] == ["happy", "xx", "yyy"]
+    assert got == [[(5.0, 2.0), (5.0, 3.0), (5.0, 2.0)]]
+    with pytest.raises(ValueError):
+        TTSService(DynamicBatcher(fn), {"a": 1}, {"v": 0}, g2p=str)        # neither embed nor embed_batch_fn
+
+
+def test_close_resolves_every_pending_future():
+    import threading
+    gate = threading.Event()
+
+    def slow(utts, alpha):
+        gate.wait(5)
+        return [np.zeros(4, np.float32) for _ in utts]
+
+    b = DynamicBatcher(slow, max_batch=1, max_wait_ms=1)
+    futs = [b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768), alpha=1.0 + i) for i in range(4)]
+    closer = threading.Thread(target=b.close)
+    closer.start()
+    gate.set()
+    closer.join(10)
+    assert not closer.is_alive()
+    for f in futs:                  # served or failed, never left hanging
+        assert f.done()
+    with pytest.raises(RuntimeError):
+        b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
+
+
 def test_token_budget_splits_batches():
     log = []
     b = DynamicBatcher(_fake_synth(log, 0.0), max_batch=64, max_wait_ms=50, max_tokens=100)
