@@ -296,7 +296,7 @@ def main():
     ap.add_argument("--sub-batches", type=int, default=0, help="am_vocoder: sub-batches per step (default 1 at N = 1, 8 at N > 1 = configs[3])")
     ap.add_argument("--phonemes", type=int, default=256)
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances for the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", default="fast", choices=["fast", "strict"],
+    ap.add_argument("--precision", default="fast", choices=["fast", "strict", "mx"],
                     help="frame-rate path: fast = fp16 MFMA operands (BASELINE configs: bf16 / fp16); strict = split precision "
                          "(3 fp16 MFMAs per product, fp32 activations)")
     ap.add_argument("--decoder-precision", default=None, choices=["f16", "f32", "x3"])
@@ -379,7 +379,7 @@ def main():
 
     roof, stages, kernels, lat, other = None, {}, {}, {}, None
     if rank == 0:
-        strict = eng.vocoder_precision == "x3"
+        strict = eng.vocoder_precision in ("x3", "mx")
         roof, stages, kernels = roofline_block(eng, work, torch, strict)
         # single-utterance latency (the reference's own call pattern, B = 1; BASELINE configs[0] is 64 phonemes): host-to-host
         # wall time of one ev_synthesize with host inputs, best of 20

@@ -310,7 +310,9 @@ int check_gemm(ev_handle* h, const ConvGemmParams& p) {
     if ((p.taps - 1) * p.dil > 64) return fail(h, "gemm: conv span %d > 64", (p.taps - 1) * p.dil);
     if (p.center * p.dil > PAD_ROWS || (p.taps - 1 - p.center) * p.dil > PAD_ROWS) return fail(h, "gemm: halo exceeds buffer slack");
     if ((p.lda * es) % 16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return fail(h, "gemm: unaligned operand");
-    if (!p.out16 && !p.out32) return fail(h, "gemm: no output");
+    if (!p.out16 && !p.out32 && !p.mxo_h) return fail(h, "gemm: no output");
+    if (p.dtype == DT_MX && (p.K % 32 || !p.W)) return fail(h, "gemm: bad MX call");
+    if (mx_check(p)) return fail(h, "gemm: inconsistent MX plane-set fields (dtype %d, N %d, K %d, taps %d)", p.dtype, p.N, p.K, p.taps);
     return 0;
 }
 int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_rows, hipStream_t st = nullptr) {
@@ -449,10 +451,36 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
     return 0;
 }
 
-struct VocBufs { Buf pre, xu[4], tmp[3], rba[3], rbb[3], nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap; };
+// raw storage of one MX plane set (ev_gemm_mx.h), sized for the largest [rows][C] it will hold; mx_view() lays a tensor into it
+struct PlaneBuf { char* h = nullptr; char* q4[2] = {nullptr, nullptr}; char* qs[2] = {nullptr, nullptr}; };
+struct MxView { char* h; char* q4[2]; char* qs[2]; unsigned qs_stride; int logC; };
+static constexpr size_t MX_PAD = 64;        // slack rows of every plane, both sides
+MxView mx_view(const PlaneBuf& b, size_t rows, int C) {
+    MxView v;
+    v.h = b.h + MX_PAD * C * 2;
+    for (int i = 0; i < 2; ++i) { v.q4[i] = b.q4[i] + MX_PAD * (C / 2); v.qs[i] = b.qs[i] + MX_PAD * 4; }
+    v.qs_stride = (unsigned)((rows + 2 * MX_PAD) * 4);
+    v.logC = ilog2(C);
+    return v;
+}
+void mx_out(ConvGemmParams& p, const MxView& v, float slope) {
+    p.mxo_h = v.h; p.mxo_q4[0] = v.q4[0]; p.mxo_q4[1] = v.q4[1]; p.mxo_qs[0] = v.qs[0]; p.mxo_qs[1] = v.qs[1];
+    p.mxo_qs_stride = v.qs_stride; p.mxo_logC = v.logC; p.mxo_slope = slope;
+}
+void mx_in(ConvGemmParams& p, const MxView& v, int C) {
+    p.A = v.h; p.lda = C; p.pro_lrelu = 0;
+    p.mx_x4[0] = v.q4[0]; p.mx_x4[1] = v.q4[1]; p.mx_xs[0] = v.qs[0]; p.mx_xs[1] = v.qs[1]; p.mx_xs_stride = v.qs_stride;
+}
+
+struct VocBufs {
+    Buf pre, xu[4], tmp[3], rba[3], rbb[3], nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap;
+    // EV_PREC_MX: plane sets of the up-conv output, conv1's output, the two alternating ResBlock states and the stage output; the
+    // planes-kernel scratch of the one fp32 tensor an MX launch reads (conv_pre's output)
+    PlaneBuf pl_xu, pl_t, pl_a, pl_b, pl_nxt; char* mx_scratch = nullptr; size_t mx_scratch_bytes = 0;
+};
 
 // weights of one generator conv: fp16 (also the "hi" part of the split) and, in the split-precision mode, the "lo" part
-int voc_weights(ev_handle* h, const std::string& base /* e.g. "voc.rb3.c1.0" */, bool x3, ConvGemmParams& p) {
+int voc_weights(ev_handle* h, const std::string& base /* e.g. "voc.rb3.c1.0" */, bool x3, ConvGemmParams& p, bool mx = false) {
     const WeightEntry* w = W(h, base + ".w16");
     const WeightEntry* b = W(h, base + ".b");
     if (!w || !b) return -1;
@@ -461,6 +489,10 @@ int voc_weights(ev_handle* h, const std::string& base /* e.g. "voc.rb3.c1.0" */,
         const WeightEntry* lo = W(h, base + ".w16l");
         if (!lo) return -1;
         p.dtype = DT_F32S; p.W_lo = lo->ptr;
+        if (mx) {           // layers with fp4 planes in the blob (N, K % 128 == 0, 3 / 7 / 11 taps: packer.py) take the MX kernel
+            auto it = h->wt.find(base + ".wmx");
+            if (it != h->wt.end()) { p.dtype = DT_MX; p.W_mx = it->second.ptr; }
+        }
     } else {
         p.dtype = DT_F16; p.W_lo = nullptr;
     }
@@ -473,9 +505,14 @@ int voc_weights(ev_handle* h, const std::string& base /* e.g. "voc.rb3.c1.0" */,
 // reference (so the Appendix-C taps are the buffers themselves) and each consumer applies its leaky-relu while staging.
 int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs& vb, bool keep) {
     const ev_config& c = h->cfg;
-    const bool x3 = c.vocoder_precision == EV_PREC_X3;
+    // EV_PREC_MX: the split-precision data flow (fp32 raw module outputs), but every layer with N, K % 128 == 0 evaluates its products as
+    // one fp16 MFMA + two block-scaled fp4 MFMAs (conv_gemm_mx_kernel) and reads its operand as the plane set its producer's epilogue wrote.
+    const bool mx = c.vocoder_precision == EV_PREC_MX;
+    const bool x3 = c.vocoder_precision == EV_PREC_X3 || mx;
     const size_t ves = x3 ? 4 : 2;
     auto set_out = [&](ConvGemmParams& q, void* dst) { if (x3) q.out32 = (float*)dst; else q.out16 = dst; };
+    auto has_mx = [&](const std::string& base) { return mx && h->wt.find(base + ".wmx") != h->wt.end(); };
+    bool prev_planes = false;           // vb.pl_nxt holds the plane set of lrelu(prev)
     ConvGemmParams p = gemm_defaults();
     if (voc_weights(h, "voc.pre", x3, p)) return -1;
     p.A = melin.p; p.lda = MEL_PAD; p.M = Rf; p.N = c.up_init_ch; p.K = MEL_PAD;
@@ -495,12 +532,23 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         const double valid_in = n_frames * U, valid_out = valid_in * s;
         // ConvTranspose1d(k = 2s, pad = s/2) == 3-tap conv with N = s * C_out, viewed as [rows_in*s][C_out] (models.py:119)
         p = gemm_defaults();
-        if (voc_weights(h, "voc.up" + std::to_string(i), x3, p)) return -1;
+        if (voc_weights(h, "voc.up" + std::to_string(i), x3, p, mx)) return -1;
         p.A = prev; p.lda = ch; p.M = rows_in; p.N = s * cout; p.K = ch; p.taps = 3; p.center = 1;
         p.row_valid = h->d_frm_valid; p.valid_shift = ilog2(U); p.ldo = s * cout;
         if (x3) { p.pro_lrelu = 1; p.pro_slope = 0.1f; }          // models.py:118 (the fp16 path has it in the producer's epilogue)
         set_out(p, vb.xu[i].p);
-        if (gemm(h, gname, p, valid_in)) return -1;
+        // the ResBlocks of this stage run on the MX kernel iff all their convs have fp4 planes (shape rule of the packer)
+        bool stage_mx = mx && cout % 128 == 0;
+        for (int j = 0; stage_mx && j < c.n_rb; ++j) stage_mx = has_mx("voc.rb" + std::to_string(i * c.n_rb + j) + ".c1.0");
+        if (p.dtype == DT_MX) {
+            if (prev_planes) mx_in(p, mx_view(vb.pl_nxt, rows_in, ch), ch);            // the previous stage's epilogue wrote lrelu(prev) as planes
+            else if (vb.mx_scratch && vb.mx_scratch_bytes >= mx_scratch_bytes(rows_in, ch)) { p.mx_scratch = vb.mx_scratch; p.mx_scratch_size = vb.mx_scratch_bytes; }
+            else p.dtype = DT_F32S;
+        }
+        if (p.dtype == DT_MX && stage_mx) mx_out(p, mx_view(vb.pl_xu, (size_t)rows_out, cout), 0.1f);      // lrelu(x) of models.py:51, shared by the three ResBlocks
+        else stage_mx = false;
+        if (gemm(h, p.dtype == DT_MX ? "voc_conv_gemm_mx" : gname, p, valid_in)) return -1;
+        const bool next_up_mx = stage_mx && i + 1 < c.n_up && has_mx("voc.up" + std::to_string(i + 1));
         U *= s;
         const int shift = ilog2(U);
         const bool last_stage = (i == c.n_up - 1);
@@ -559,7 +607,17 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                 const std::string c1 = rb + ".c1." + std::to_string(d), c2 = rb + ".c2." + std::to_string(d);
                 // fused pair kernels: C = 32 (every k) and C = 64 with k = 3 (the HBM-bound end of the generator; fp16 mode only)
                 const bool fused = !x3 && ((cout == 32 && (k == 3 || k == 7 || k == 11)) || (cout == 64 && k == 3)) && !getenv("EV_NO_FUSED_PAIR");
-                if (!fused) {
+                if (stage_mx) {
+                    // MX stage: xt only ever exists as conv2's operand planes; x travels as fp32 (the residual) + the planes of lrelu(x)
+                    const PlaneBuf& xin = d == 0 ? vb.pl_xu : ((d - 1) % 2 == 0 ? vb.pl_a : vb.pl_b);
+                    p = gemm_defaults();
+                    if (voc_weights(h, c1, x3, p, true) || p.dtype != DT_MX) return fail(h, "MX stage: %s has no fp4 planes", c1.c_str());
+                    mx_in(p, mx_view(xin, (size_t)rows_out, cout), cout);
+                    p.M = rows_out; p.N = cout; p.K = cout; p.taps = k; p.dil = dil; p.center = (k - 1) / 2;
+                    p.row_valid = h->d_frm_valid; p.valid_shift = shift; p.act = ACT_LRELU; p.act_slope = 0.1f; p.ldo = cout;
+                    mx_out(p, mx_view(vb.pl_t, (size_t)rows_out, cout), 1.0f);
+                    if (gemm(h, "voc_conv_gemm_mx", p, valid_out, sj)) return -1;
+                } else if (!fused) {
                     // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
                     p = gemm_defaults();
                     if (voc_weights(h, c1, x3, p)) return -1;
@@ -572,14 +630,19 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                 }
                 // x = c2(xt) + x  (models.py:54-56)
                 p = gemm_defaults();
-                if (voc_weights(h, c2, x3, p)) return -1;
+                if (voc_weights(h, c2, x3, p, stage_mx)) return -1;
                 p.A = vb.tmp[bj].p; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
+                if (stage_mx) {
+                    if (p.dtype != DT_MX) return fail(h, "MX stage: %s has no fp4 planes", c2.c_str());
+                    mx_in(p, mx_view(vb.pl_t, (size_t)rows_out, cout), cout);
+                }
                 p.taps = k; p.dil = 1; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
                 p.res = xcur; p.res_dtype = x3 ? DT_F32 : DT_F16; p.ldres = cout; p.ldo = cout;
                 if (d + 1 < c.n_rb_dils) {
                     void* dst = (d % 2 == 0) ? vb.rba[bj].p : vb.rbb[bj].p;
                     set_out(p, dst);
                     xcur = dst;
+                    if (stage_mx) mx_out(p, mx_view(d % 2 == 0 ? vb.pl_a : vb.pl_b, (size_t)rows_out, cout), 0.1f);     // the next conv1's operand
                 } else {
                     // MRF: xs += resblock(x); x = xs / num_kernels (models.py:121-126), then the next leaky_relu
                     // fp16 mode with three ResBlocks (the reference config): the first two scaled branches are kept in fp16 and the
@@ -596,6 +659,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                         else p.out32 = (float*)vb.mrf32.p;
                     } else if (x3) {
                         p.out32 = (float*)vb.nxt[i].p;               // raw MRF mean (= the voc_mrf tap); consumers apply the leaky-relu
+                        if (next_up_mx) mx_out(p, mx_view(vb.pl_nxt, (size_t)rows_out, cout), 0.1f);      // ... or read these planes (models.py:118)
                     } else {
                         p.post_lrelu = 1; p.post_slope = last_stage ? 0.01f : 0.1f;   // models.py:118 / :127
                         p.out16 = vb.nxt[i].p;
@@ -619,12 +683,13 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0, sj, &shape);
                     if (cout == 32) launch_resblock_pair_c32(rp, sj);
                     else launch_resblock_pair_c64(rp, sj);
-                } else if (gemm(h, gname, p, valid_out * frac, sj)) return -1;
+                } else if (gemm(h, p.dtype == DT_MX ? "voc_conv_gemm_mx" : gname, p, valid_out * frac, sj)) return -1;
             }
             if (conc && j < 2) (void)hipEventRecord(h->ev_join[j], h->aux[j]);
         }
         }   // row chunks
         prev = vb.nxt[i].p;
+        prev_planes = next_up_mx;
         ch = cout;
     }
     WPTR(wpost, float, "voc.post.w");
@@ -640,7 +705,8 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
 int total_up(const ev_config& c) { int u = 1; for (int i = 0; i < c.n_up; ++i) u *= c.up_rates[i]; return u; }
 
 void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs& vb) {
-    const bool x3 = c.vocoder_precision == EV_PREC_X3;
+    const bool mx = c.vocoder_precision == EV_PREC_MX;
+    const bool x3 = c.vocoder_precision == EV_PREC_X3 || mx;
     const size_t ves = x3 ? 4 : 2;
     vb.pre = ap.rows(Rf, c.up_init_ch, ves);
     if (keep && !x3) vb.pre_tap = ap.rows(Rf, c.up_init_ch, 4);
@@ -671,6 +737,25 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
     for (int j = 0; j < (per_rb ? 3 : 1); ++j) { vb.tmp[j] = mk2(ves); vb.rba[j] = mk2(ves); vb.rbb[j] = mk2(ves); }
     if (per_rb) { vb.mrf16a = mk2(2); vb.mrf16b = mk2(2); } else vb.mrf32 = mk2(4);
     vb.wavrows = ap.rows((size_t)Rf * total_up(c), 1, 4);
+    if (mx) {
+        // plane sets, re-used across the stages that run on the MX kernel (C % 128 == 0): sized by the largest
+        size_t hb = 0, qb = 0, sb = 0;
+        ch = c.up_init_ch; U = 1;
+        for (int i = 0; i < c.n_up; ++i) {
+            U *= c.up_rates[i]; ch /= 2;
+            if (ch % 128) continue;
+            const size_t R = (size_t)Rf * U + 2 * MX_PAD;
+            hb = std::max(hb, R * ch * 2); qb = std::max(qb, R * (ch / 2)); sb = std::max(sb, (size_t)(ch / 128) * R * 4);
+        }
+        PlaneBuf* sets[5] = {&vb.pl_xu, &vb.pl_t, &vb.pl_a, &vb.pl_b, &vb.pl_nxt};
+        for (PlaneBuf* b : sets) {
+            if (!hb) break;
+            b->h = ap.take(hb);
+            for (int i = 0; i < 2; ++i) { b->q4[i] = ap.take(qb); b->qs[i] = ap.take(sb); }
+        }
+        vb.mx_scratch_bytes = (c.up_init_ch % 128 == 0) ? mx_scratch_bytes(Rf, c.up_init_ch) : 0;
+        vb.mx_scratch = vb.mx_scratch_bytes ? ap.take(vb.mx_scratch_bytes) : nullptr;
+    }
 }
 
 // frame layout from mel lengths (host) -> device maps; returns Rf
@@ -784,8 +869,8 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
     }
     if (cfg->decoder_precision != EV_PREC_F16 && cfg->decoder_precision != EV_PREC_F32 && cfg->decoder_precision != EV_PREC_X3)
         return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
-    if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3)
-        return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16 or EV_PREC_X3");
+    if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3 && cfg->vocoder_precision != EV_PREC_MX)
+        return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16, EV_PREC_X3 or EV_PREC_MX");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));
@@ -917,7 +1002,7 @@ static int finish_wav(ev_handle* h, VocBufs& vb, float* d_wav, int16_t* d_i16, i
 
 static void register_voc_taps(ev_handle* h, VocBufs& vb) {
     const ev_config& c = h->cfg;
-    const bool x3 = c.vocoder_precision == EV_PREC_X3;      // split-precision mode: the stored tensors ARE the raw module outputs
+    const bool x3 = c.vocoder_precision != EV_PREC_F16;     // split-precision / MX modes: the stored tensors ARE the raw module outputs
     add_tap(h, "voc_pre", x3 ? vb.pre.p : vb.pre_tap.p, DT_F32, c.up_init_ch, c.up_init_ch, 1, 0);
     int ch = c.up_init_ch, U = 1;
     for (int i = 0; i < c.n_up; ++i) {
@@ -933,7 +1018,7 @@ int ev_vocoder(ev_handle* h, int B, const void* mel, int mel_is_f16, const int32
     HIPCHK(h, hipSetDevice(h->device));
     const ev_config& c = h->cfg;
     const bool keep = c.keep_stages != 0;
-    const bool voc_x3 = c.vocoder_precision == EV_PREC_X3;
+    const bool voc_x3 = c.vocoder_precision != EV_PREC_F16;      // X3 and MX: fp32 mel rows
     const int U = total_up(c);
     profiling_reset(h);
     h->taps.clear();
@@ -999,7 +1084,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     const bool keep = c.keep_stages != 0;
     const bool dev_in = (flags & EV_FLAG_DEVICE_INPUTS) != 0;
     const int dec_prec = c.decoder_precision == EV_PREC_F16 ? DT_F16 : DT_F32;      // X3 and F32 both keep fp32 activations
-    const bool voc_x3 = c.vocoder_precision == EV_PREC_X3;
+    const bool voc_x3 = c.vocoder_precision != EV_PREC_F16;      // X3 and MX: fp32 mel rows
     profiling_reset(h);
     h->taps.clear();
     h->B = B;
@@ -1378,8 +1463,10 @@ int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* stream) {
     memcpy(&p, d, sizeof p);
     const int es = p.dtype == DT_F16 ? 2 : 4;
     if (p.M % ROW_ALIGN || p.N % 32 || (p.K * es) % 64 || (p.taps - 1) * p.dil > 64) return -2;
-    if ((p.dtype == DT_F32S || p.dtype == DT_MX) && (p.K % 32 || !p.W_lo)) return -2;
-    if (p.dtype == DT_MX && p.W_mx && (!p.mx_scratch || p.mx_scratch_size < mx_scratch_bytes(p.M, p.K))) return -2;
+    if (p.dtype == DT_F32S && (p.K % 32 || !p.W_lo)) return -2;
+    if (p.dtype == DT_MX && (p.K % 32 || !p.W)) return -2;
+    if (mx_check(p)) return -2;
+    if (!p.out16 && !p.out32 && !p.mxo_h) return -2;
     if (p.pro_lrelu && !(p.pro_slope >= 0.f && p.pro_slope <= 1.f)) return -2;
     launch_conv_gemm(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -258,7 +258,54 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 // of stores per iteration is a compile-time constant and the counted vmcnt waits of the prefetches never drain them.
 // LEAN: the operands of a pass are requested at the top of THAT pass instead of one pass ahead (one register set instead of two:
 // the MRF variant of the 128-register phased kernel, whose epilogue is covered by the CU's other block anyway).
-enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64, EPI_ADD16 = 128, EPI_LEAN = 256 };
+// MXP: additionally (or, without O32 / O16, only) the MX plane set of lrelu(result, mxo_slope) for a DT_MX consumer (mx_emit_planes).
+enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64, EPI_ADD16 = 128, EPI_LEAN = 256,
+       EPI_MXP = 512 };
+
+// ---- MX plane set of an activation (format: ev_gemm_mx.h / emotivoice_amd/mxfp4.py).  E8M0 byte of the block scale 2^(floor(log2 amax) - 2),
+// clamped to [1, 254] (an all-zero block gets 1).
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 2;
+    return (unsigned)min(max(e, 1), 254);
+}
+// One lane = 8 consecutive channels a[0..3] (packed pairs) at linear element offset `lin` of the [rows][C] tensor; the four lanes of a
+// 32-channel block (consecutive lanes, lane & 3 = position in the block) agree on the block maxima by two quad shuffles.  Writes 16 B of the
+// fp16 hi plane, 4 B of each code plane and (first lane of the block) one byte of each scale plane.
+__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, int lane) {
+    half2v hh[4];
+    f32x2 hf[4], lf[4];
+    float mh = 0.f, ml = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hh[j] = __builtin_convertvector(a[j], half2v);
+        hf[j] = __builtin_convertvector(hh[j], f32x2);
+        lf[j] = a[j] - hf[j];
+        mh = max_raw(mh, max_raw(__builtin_fabsf(hf[j][0]), __builtin_fabsf(hf[j][1])));
+        ml = max_raw(ml, max_raw(__builtin_fabsf(lf[j][0]), __builtin_fabsf(lf[j][1])));
+    }
+    mh = max_raw(mh, __shfl_xor(mh, 1)); mh = max_raw(mh, __shfl_xor(mh, 2));
+    ml = max_raw(ml, __shfl_xor(ml, 1)); ml = max_raw(ml, __shfl_xor(ml, 2));
+    const unsigned bh = mx_scale_byte(mh), bl = mx_scale_byte(ml);
+    const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);       // the block scales as fp32 (2^(b - 127))
+    unsigned ch = 0, cl = 0;                                                           // v_cvt_scalef32_pk_fp4_f32: fp4(x / scale), RNE, saturating
+    ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[0][0], hf[0][1], sh, 0); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[0][0], lf[0][1], sl, 0);
+    ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[1][0], hf[1][1], sh, 1); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[1][0], lf[1][1], sl, 1);
+    ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[2][0], hf[2][1], sh, 2); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[2][0], lf[2][1], sl, 2);
+    ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[3][0], hf[3][1], sh, 3); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[3][0], lf[3][1], sl, 3);
+    uint4 ho;
+    ho.x = *reinterpret_cast<unsigned*>(&hh[0]); ho.y = *reinterpret_cast<unsigned*>(&hh[1]);
+    ho.z = *reinterpret_cast<unsigned*>(&hh[2]); ho.w = *reinterpret_cast<unsigned*>(&hh[3]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho;
+    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
+    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;
+    if ((lane & 3) == 0) {
+        const long row = lin >> p.mxo_logC;
+        const unsigned c = (unsigned)lin & ((1u << p.mxo_logC) - 1u);
+        const long so = (long)(c >> 7) * p.mxo_qs_stride + row * 4 + ((c >> 5) & 3);
+        reinterpret_cast<uint8_t*>(p.mxo_qs[0])[so] = (uint8_t)bh;
+        reinterpret_cast<uint8_t*>(p.mxo_qs[1])[so] = (uint8_t)bl;
+    }
+}
 __device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
 template <int MT, int NT, int EPI>
@@ -323,6 +370,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     const f32x2 out_scale2 = f32x2{p.out_scale, p.out_scale};
     const bool has_post = p.post_lrelu != 0;
     const f32x2 post_slope2 = f32x2{p.post_slope, p.post_slope};
+    const f32x2 mxo_slope2 = f32x2{p.mxo_slope, p.mxo_slope};
     __half* const o16 = reinterpret_cast<__half*>(p.out16);
     float* const o32a = p.out32_before_post ? p.out32 : nullptr;
     float* const o32b = p.out32_before_post ? nullptr : p.out32;
@@ -420,6 +468,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 // zero rows outside the utterances: on the packed words (4 selects instead of 8)
                 o.x = valid ? o.x : 0u; o.y = valid ? o.y : 0u; o.z = valid ? o.z : 0u; o.w = valid ? o.w : 0u;
                 *reinterpret_cast<uint4*>(o16 + off) = o;
+            }
+            if constexpr (EPI & EPI_MXP) {            // the consumer's leaky-relu, then its operand planes (ldo == N: `off` is the linear offset)
+                f32x2 am[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { am[j] = lrelu2(v[j], mxo_slope2); am[j][0] = valid ? am[j][0] : 0.f; am[j][1] = valid ? am[j][1] : 0.f; }
+                mx_emit_planes(p, am, off, lane);
             }
             EV_STAMP()
         }

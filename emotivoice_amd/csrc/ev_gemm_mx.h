@@ -24,8 +24,9 @@
 // of waves 4-7, which in the fp16 pass only re-reads the slab's last row (rows 320..383 of a slab buffer are never read by a
 // fragment): same piece count per wave in every pass, so every vmcnt immediate stays what it was.
 //
-// Activation planes are produced by mx_planes_kernel (leaky-relu of the consumer, fp16 hi plane, fp4 codes of hi and of the fp32
-// remainder, scales) from the fp32 tensor; fusing that into the producer's epilogue is the next step.
+// Activation planes come from the PRODUCER's epilogue (EPI_MXP / mx_emit_planes in ev_gemm.hip: the consumer's leaky-relu, fp16 hi plane,
+// fp4 codes of hi and of the fp32 remainder, scales -- 3.06 bytes per element instead of fp32's 4, and no tensor pass of its own), or,
+// for an fp32 input that some other kernel wrote (conv_pre's output, the op tests), from mx_planes_kernel.
 #pragma once
 
 static constexpr int MX_SLACK = 64;          // readable rows in front of / behind every plane (the conv halo of the first / last tile)
@@ -52,10 +53,6 @@ __device__ __forceinline__ unsigned mx_fp4_code(float y) {          // |y| <= 6 
     const float a = fabsf(y);
     unsigned c = (a > 0.25f) + (a >= 0.75f) + (a > 1.25f) + (a >= 1.75f) + (a > 2.5f) + (a >= 3.5f) + (a > 5.0f);
     return c | ((__float_as_uint(y) >> 28) & 8u);
-}
-__device__ __forceinline__ unsigned mx_scale_byte(float amax) {     // E8M0 byte of 2^(floor(log2 amax) - 2), clamped to [1, 254]
-    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 2;
-    return (unsigned)min(max(e, 1), 254);
 }
 __global__ __launch_bounds__(256) void mx_planes_kernel(const float* __restrict__ A, int lda, int M, int K, int pro, float slope,
                                                         __half* __restrict__ H, uint8_t* __restrict__ x4h, uint8_t* __restrict__ x4l,
@@ -103,8 +100,6 @@ __device__ __forceinline__ void mfma_mx_inplace(f32x4& c, const uint4& a, const 
                  : "+v"(c) : "v"(*reinterpret_cast<const u32x4*>(&a)), "v"(*reinterpret_cast<const u32x4*>(&b)), "v"(sa), "v"(sb));
 }
 
-// one chunk's operand sources: uniform bases (SGPR pairs), the shift that turns the fp4-plane lane offsets into fp16-plane ones
-struct MxChunk { const char* xb; const char* wb; const char* sc; unsigned sh; };
 
 // LDS of a slab buffer: rows 0..319 of 64 B (fragments), [20 KB, 22 KB): activation scales (4 B per slab row, from row (m0 - c d) & ~3),
 // [22 KB, 24 KB): weight scales [tap][128]
@@ -167,26 +162,25 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const char* const swh = uniform_ptr(wmx + 2 * nw4 + nws + (size_t)nt * nkc4 * TAPS * 128);
     const unsigned xs_stride = p.mx_xs_stride;
 
-    auto chunk_of = [&](int q) -> MxChunk {
-        MxChunk c;
-        if (q < nkc16) { c.xb = xb16 + (unsigned)q * 64u; c.wb = wb16 + (unsigned)q * 64u; c.sc = nullptr; c.sh = 2; return c; }
-        q -= nkc16;
-        const bool second = q >= nkc4;
-        const unsigned kc = second ? q - nkc4 : q;
-        c.xb = (second ? xb4l : xb4h) + kc * 64u;
-        c.wb = (second ? wb4h : wb4l) + kc * 64u;
-        c.sc = wave < 6 ? (second ? sxl : sxh) + kc * xs_stride : (second ? swh : swl) + kc * (unsigned)(TAPS * 128);      // (32-bit products: scalar)
-        c.sh = 0;
-        return c;
-    };
+    // Operand sources of a chunk are plain scalar arithmetic on these bases (two-way uniform selects at most: a lambda returning a struct
+    // of pointers picked three ways became a table in SCRATCH, indexed inside the loop).  The second fp4 pass is the first one shifted by
+    // constant byte distances.
+    const long dx4 = (long)(xb4l - xb4h), dw4 = (long)nw4;
+    const bool scw = wave >= 4;                                                            // this wave's third slab piece carries scales
+    const char* const sc0 = uniform_ptr(wave < 6 ? sxh : swl);
+    const long dsc = wave < 6 ? (long)(sxl - sxh) : (long)nws;
+    const unsigned scstep = wave < 6 ? xs_stride : (unsigned)(TAPS * 128);
 
     const unsigned xdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024), wdst = xdst + 2 * XBUF;
-    // weight tile of tap US of chunk C -> ring slot SLOT; slab piece I of chunk C -> slab buffer BUF
-#define EV_MX_ISSUE_W(C, US, SLOT) glds16((C).wb + (unsigned)(US) * (K2 << (C).sh), (wrK << (C).sh) + pp16, wdst + (unsigned)(SLOT) * WBUF);
-#define EV_MX_ISSUE_X(C, BUF, I)                                                                                   \
-    {                                                                                                              \
-        if ((I) == 2 && (C).sh == 0 && wave >= 4) glds16((C).sc, scv, xdst + (unsigned)(BUF) * XBUF + (I) * 8192); \
-        else glds16((C).xb, (rsK[I] << (C).sh) + pp16, xdst + (unsigned)(BUF) * XBUF + (I) * 8192);                 \
+    // weight tile of tap US (base WB, pitch shift SH) -> ring slot SLOT; slab piece I (base XB / scale run SC, next chunk) -> slab buffer BUF.
+    // No `if` around an issue: an asm statement under a condition becomes a real branch inside the MFMA sequence; the operands are selected.
+#define EV_MX_ISSUE_W(WB, SH, US, SLOT) glds16((WB) + (unsigned)(US) * (K2 << (SH)), (wrK << (SH)) + pp16, wdst + (unsigned)(SLOT) * WBUF);
+#define EV_MX_ISSUE_X(XB, SC, SH, ISMX, BUF, I)                                                                      \
+    {                                                                                                                \
+        if constexpr ((I) == 2) {                                                                                    \
+            const bool sc_ = (ISMX) && scw;                                                                          \
+            glds16(sc_ ? (SC) : (XB), sc_ ? scv : (rsK[2] << (SH)) + pp16, xdst + (unsigned)(BUF) * XBUF + 2 * 8192); \
+        } else glds16((XB), (rsK[I] << (SH)) + pp16, xdst + (unsigned)(BUF) * XBUF + (I) * 8192);                     \
     }
 
     f32x4 acc[NT][MT];
@@ -199,24 +193,28 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const int ws_off = MX_WS_OFF + wc * TC + fr;                       // + tap * 128 + a * 16
     const int xs_off = MX_XS_OFF + (wt * 64 + fr + soff) * 4 + fq;     // + (tap * dil + b * 16) * 4
 
-    MxChunk cur = chunk_of(0), nxt = chunk_of(nq > 1 ? 1 : 0);
-    EV_MX_ISSUE_X(cur, 0, 0)
-    EV_MX_ISSUE_X(cur, 0, 1)
-    EV_MX_ISSUE_X(cur, 0, 2)
-    EV_MX_ISSUE_W(cur, 0, 0)
-    EV_MX_ISSUE_W(cur, 1, 1)
-    EV_MX_ISSUE_W(cur, 2, 2)
+    EV_MX_ISSUE_X(xb16, sc0, 2u, false, 0, 0)
+    EV_MX_ISSUE_X(xb16, sc0, 2u, false, 0, 1)
+    EV_MX_ISSUE_X(xb16, sc0, 2u, false, 0, 2)
+    EV_MX_ISSUE_W(wb16, 2u, 0, 0)
+    EV_MX_ISSUE_W(wb16, 2u, 1, 1)
+    EV_MX_ISSUE_W(wb16, 2u, 2, 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wc == 1) __builtin_amdgcn_s_barrier();
 
     // One (chunk, tap) step; see conv_gemm_phased_body for the schedule (requests inside the matrix phase, fragment reads retired by the
-    // compiler's own lgkmcnt in front of the first MFMA, two barriers per step).  MX: true in the fp4 passes.
-#define EV_MX_STEP(MX, u)                                                                                               \
+    // compiler's own lgkmcnt in front of the first MFMA, two barriers per step).  MX: true in the fp4 passes.  In scope: cwb (this chunk's
+    // weight base), CSH (its pitch shift, static), nwb / nsh / nxb / nsc / nmx (the next chunk's), more, Xb, dil_, sbase, q.
+#define EV_MX_STEP(MX, CSH, u)                                                                                          \
     {                                                                                                                   \
         const int s = sbase + (u);                                                                                      \
-        const bool in_cur = ((u) + 3 < U) || !more;                                                                     \
-        const int u3 = ((u) + 3 < U) ? (u) + 3 : (more ? (u) + 3 - U : U - 1);                                          \
+        const bool in_cur_static = ((u) + 3 < U);                                                                       \
+        const bool in_cur = in_cur_static || !more;                                                                     \
+        const int u3 = in_cur_static ? (u) + 3 : (more ? (u) + 3 - U : U - 1);                                          \
+        const char* const wsel = in_cur_static ? cwb : (more ? nwb : cwb);                                              \
+        const unsigned wsh = in_cur_static ? (unsigned)(CSH) : (more ? nsh : (unsigned)(CSH));                          \
+        (void)in_cur;                                                                                                   \
         uint4 xf[MT], wf[NT];                                                                                           \
         int xsc[MT], wsc[NT];                                                                                           \
         {                                                                                                               \
@@ -240,11 +238,11 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
                 if constexpr (MX) mfma_mx_inplace(acc[a][b], wf[a], xf[b], wsc[a], xsc[b]);                             \
                 else mfma_inplace(acc[a][b], *reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf[b]));     \
                 const int idx = a * MT + b;                                                                             \
-                if (idx == 2) { if (in_cur) { EV_MX_ISSUE_W(cur, u3, (s + 3) & 3) } else { EV_MX_ISSUE_W(nxt, u3, (s + 3) & 3) } } \
+                if (idx == 2) { EV_MX_ISSUE_W(wsel, wsh, u3, (s + 3) & 3) }                                             \
                 if ((u) == 0 && more) {                                                                                 \
-                    if (idx == 4) { EV_MX_ISSUE_X(nxt, (q + 1) & 1, 0) }                                                \
-                    if (idx == 5) { EV_MX_ISSUE_X(nxt, (q + 1) & 1, 1) }                                                \
-                    if (idx == 6) { EV_MX_ISSUE_X(nxt, (q + 1) & 1, 2) }                                                \
+                    if (idx == 4) { EV_MX_ISSUE_X(nxb, nsc, nsh, nmx, (q + 1) & 1, 0) }                                 \
+                    if (idx == 5) { EV_MX_ISSUE_X(nxb, nsc, nsh, nmx, (q + 1) & 1, 1) }                                 \
+                    if (idx == 6) { EV_MX_ISSUE_X(nxb, nsc, nsh, nmx, (q + 1) & 1, 2) }                                 \
                 }                                                                                                       \
             }                                                                                                           \
         }                                                                                                               \
@@ -257,27 +255,39 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     // two loops, not one loop with an fp16 / fp4 branch: with both bodies behind a branch hipcc gave the accumulators different registers on the
     // two paths (64 moves per chunk and 80-150 spilled registers); back to back they simply flow from the first loop into the second
     int sbase = 0, q = 0;
-    for (; q < nkc16; ++q) {
-        const bool more = q + 1 < nq;
+    for (int kc = 0; kc < nkc16; ++kc, ++q) {            // fp16 pass; a next chunk always exists (K % 128 == 0: nkc4 >= 1)
+        const bool more = true, lastc = kc + 1 == nkc16;
+        const char* const cwb = wb16 + (unsigned)kc * 64u;
+        const char* const nxb = uniform_ptr(lastc ? xb4h : xb16 + (unsigned)(kc + 1) * 64u);
+        const char* const nwb = uniform_ptr(lastc ? wb4l : wb16 + (unsigned)(kc + 1) * 64u);
+        const char* const nsc = sc0;
+        const unsigned nsh = lastc ? 0u : 2u;
+        const bool nmx = lastc;
         const char* const Xb = Xs + (q & 1) * XBUF;
         int dil_ = p.dil;
         asm volatile("" : "+s"(dil_));            // (opaque per chunk: keeps hipcc from hoisting the fragment addresses of all taps)
 #pragma unroll
-        for (int u = 0; u < U; ++u) EV_MX_STEP(false, u)
+        for (int u = 0; u < U; ++u) EV_MX_STEP(false, 2, u)
         sbase += U;
-        cur = nxt;
-        nxt = chunk_of(q + 2 < nq ? q + 2 : nq - 1);
     }
-    for (; q < nq; ++q) {
-        const bool more = q + 1 < nq;
+    const int n4 = 2 * nkc4;
+    for (int q4 = 0; q4 < n4; ++q4, ++q) {               // Q(wl).Q(xh) over the K chunks, then Q(wh).Q(xl)
+        const bool more = q4 + 1 < n4;
+        const int qn = more ? q4 + 1 : q4;
+        const bool sec = q4 >= nkc4, secn = qn >= nkc4;
+        const unsigned kc = (unsigned)(sec ? q4 - nkc4 : q4), kn = (unsigned)(secn ? qn - nkc4 : qn);
+        const char* const cwb = uniform_ptr(wb4l + (sec ? dw4 : 0L) + kc * 64u);
+        const char* const nxb = uniform_ptr(xb4h + (secn ? dx4 : 0L) + kn * 64u);
+        const char* const nwb = uniform_ptr(wb4l + (secn ? dw4 : 0L) + kn * 64u);
+        const char* const nsc = uniform_ptr(sc0 + (secn ? dsc : 0L) + kn * scstep);
+        constexpr unsigned nsh = 0u;
+        constexpr bool nmx = true;
         const char* const Xb = Xs + (q & 1) * XBUF;
         int dil_ = p.dil;
         asm volatile("" : "+s"(dil_));
 #pragma unroll
-        for (int u = 0; u < U; ++u) EV_MX_STEP(true, u)
+        for (int u = 0; u < U; ++u) EV_MX_STEP(true, 0, u)
         sbase += U;
-        cur = nxt;
-        nxt = chunk_of(q + 2 < nq ? q + 2 : nq - 1);
     }
 #undef EV_MX_STEP
 #undef EV_MX_ISSUE_W
@@ -297,26 +307,40 @@ static void launch_mx_epi(const ConvGemmParams& p, hipStream_t s) {
     const int grid = (p.M / PH_BM) * (p.N / 128);
     hipLaunchKernelGGL((conv_gemm_mx_kernel<TAPS, EPI>), dim3(grid), dim3(512), PH_LDS, s, p);
 }
-template <int TAPS>
-static void launch_mx_taps(const ConvGemmParams& p, hipStream_t s) {
-    // the split-precision path's epilogue variants (fp32 output); the operand-heavy ones one pass at a time (128 registers)
+// epilogue variant of a DT_MX launch, or -1: fp32 output with the split-precision path's operand sets, each with or without the plane
+// set of the result (EPI_MXP); planes-only for conv1 of a ResBlock pair (its fp32 value has no other reader)
+static int mx_epi_variant(const ConvGemmParams& p) {
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
     const bool odd_slope = p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f);
-    const bool o32 = p.out32 && !p.out16 && !p.out32_before_post && !p.post_lrelu;
-    const bool plain = !p.seq_bias && !p.add16_a && o32 && !odd_slope;
+    const bool mxp = p.mxo_h != nullptr;
+    if (mxp && !(p.mxo_q4[0] && p.mxo_q4[1] && p.mxo_qs[0] && p.mxo_qs[1] && p.ldo == p.N && p.mxo_logC >= 7 && p.mxo_logC <= 12 &&
+                 p.N % (1 << p.mxo_logC) == 0 && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f)) return -1;
+    if (p.seq_bias || p.add16_a || p.out16 || p.out32_before_post || p.post_lrelu || odd_slope || rare_act) return mxp ? -1 : EPI_GENERIC;
     const bool res32 = p.res && p.res_dtype == DT_F32;
-    if (plain && !p.acc32 && !p.res && !rare_act) return launch_mx_epi<TAPS, EPI_O32>(p, s);
-    if (plain && !p.acc32 && !p.res && rare_act) return launch_mx_epi<TAPS, EPI_RARE_ACT | EPI_O32>(p, s);
-    if (plain && !p.acc32 && res32 && !rare_act) return launch_mx_epi<TAPS, EPI_RES32 | EPI_O32 | EPI_LEAN>(p, s);
-    if (plain && p.acc32 && res32 && !rare_act) return launch_mx_epi<TAPS, EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN>(p, s);
-    launch_mx_epi<TAPS, EPI_GENERIC>(p, s);
+    if (p.res && !res32) return mxp ? -1 : EPI_GENERIC;
+    const int m = mxp ? EPI_MXP : 0;
+    if (!p.out32) return (mxp && !p.res && !p.acc32) ? EPI_MXP : -1;
+    if (!p.acc32 && !p.res) return EPI_O32 | m;
+    if (!p.acc32 && res32) return EPI_RES32 | EPI_O32 | EPI_LEAN | m;
+    if (p.acc32 && res32) return EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | m;
+    return mxp ? -1 : EPI_GENERIC;
+}
+#define EV_MX_VARIANTS(X) X(EPI_O32) X(EPI_RES32 | EPI_O32 | EPI_LEAN) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_MXP) X(EPI_O32 | EPI_MXP) \
+    X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_GENERIC)
+template <int TAPS>
+static void launch_mx_taps(const ConvGemmParams& p, int e, hipStream_t s) {
+    switch (e) {
+#define EV_MX_CASE(E) case (E): launch_mx_epi<TAPS, (E)>(p, s); break;
+        EV_MX_VARIANTS(EV_MX_CASE)
+#undef EV_MX_CASE
+        default: break;
+    }
 }
 template <int TAPS>
 static hipError_t mx_attr_taps() {
     hipError_t e = hipSuccess, r;
 #define EV_MX_ATTR(E) r = hipFuncSetAttribute((const void*)conv_gemm_mx_kernel<TAPS, (E)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
-    EV_MX_ATTR(EPI_O32) EV_MX_ATTR(EPI_RARE_ACT | EPI_O32) EV_MX_ATTR(EPI_RES32 | EPI_O32 | EPI_LEAN)
-    EV_MX_ATTR(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN) EV_MX_ATTR(EPI_GENERIC)
+    EV_MX_VARIANTS(EV_MX_ATTR)
 #undef EV_MX_ATTR
     return e;
 }
@@ -330,29 +354,44 @@ static hipError_t mx_set_attributes() {
 
 // Which calls take the MX kernel is a function of the layer's shape only (never of M): an utterance gets the same arithmetic alone
 // and inside a batch.  Everything else of a DT_MX call runs as the split-precision (three fp16 MFMAs) kernel.
+static bool mx_shape_ok(const ConvGemmParams& p) {
+    return p.W_mx && p.N % 128 == 0 && p.K % 128 == 0 && (p.taps == 3 || p.taps == 7 || p.taps == 11) && p.M % PH_BM == 0 &&
+           p.lda == p.K && (p.taps - 1) * p.dil <= MAX_SPAN;
+}
+static bool mx_planes_in(const ConvGemmParams& p) { return p.mx_x4[0] != nullptr; }
 static bool mx_eligible(const ConvGemmParams& p) {
-    return p.W_mx && p.mx_scratch && p.N % 128 == 0 && p.K % 128 == 0 && (p.taps == 3 || p.taps == 7 || p.taps == 11) && p.M % PH_BM == 0 &&
-           p.lda == p.K && (p.taps - 1) * p.dil <= MAX_SPAN && p.mx_scratch_size >= mx_scratch_bytes(p.M, p.K);
+    if (!mx_shape_ok(p) || mx_epi_variant(p) < 0) return false;
+    if (mx_planes_in(p)) return p.mx_x4[1] && p.mx_xs[0] && p.mx_xs[1] && !p.pro_lrelu;
+    return p.mx_scratch && p.mx_scratch_size >= mx_scratch_bytes(p.M, p.K);
+}
+// 0 = this DT_MX call can run (as the MX kernel, or -- fp32 input, no plane output -- as the split-precision fallback)
+int mx_check(const ConvGemmParams& p) {
+    if (p.dtype != DT_MX) return p.mxo_h || mx_planes_in(p) ? -1 : 0;       // plane sets exist only between DT_MX launches
+    if (mx_eligible(p)) return 0;
+    return (p.mxo_h || mx_planes_in(p) || !p.W_lo) ? -1 : 0;
 }
 static void launch_mx(const ConvGemmParams& p_in, hipStream_t s) {
     ConvGemmParams p = p_in;
-    const MxPlaneLayout L = mx_layout(p.M, p.K);
-    char* const base = reinterpret_cast<char*>(p.mx_scratch);
-    const size_t r0 = MX_SLACK;
-    __half* H = reinterpret_cast<__half*>(base + L.h + r0 * p.K * 2);
-    uint8_t* x4h = reinterpret_cast<uint8_t*>(base + L.x4h + r0 * (p.K / 2));
-    uint8_t* x4l = reinterpret_cast<uint8_t*>(base + L.x4l + r0 * (p.K / 2));
-    uint8_t* sh = reinterpret_cast<uint8_t*>(base + L.sh + r0 * 4);
-    uint8_t* sl = reinterpret_cast<uint8_t*>(base + L.sl + r0 * 4);
-    const unsigned s_stride = (unsigned)(L.rows * 4);
-    const long threads = (long)p.M * (p.K / 8);
-    hipLaunchKernelGGL(mx_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(p.A), p.lda, p.M, p.K,
-                       p.pro_lrelu, p.pro_slope, H, x4h, x4l, sh, sl, s_stride);
-    p.A = H; p.lda = p.K; p.pro_lrelu = 0;
-    p.mx_x4[0] = x4h; p.mx_x4[1] = x4l; p.mx_xs[0] = sh; p.mx_xs[1] = sl; p.mx_xs_stride = s_stride;
+    if (!mx_planes_in(p)) {
+        const MxPlaneLayout L = mx_layout(p.M, p.K);
+        char* const base = reinterpret_cast<char*>(p.mx_scratch);
+        const size_t r0 = MX_SLACK;
+        __half* H = reinterpret_cast<__half*>(base + L.h + r0 * p.K * 2);
+        uint8_t* x4h = reinterpret_cast<uint8_t*>(base + L.x4h + r0 * (p.K / 2));
+        uint8_t* x4l = reinterpret_cast<uint8_t*>(base + L.x4l + r0 * (p.K / 2));
+        uint8_t* sh = reinterpret_cast<uint8_t*>(base + L.sh + r0 * 4);
+        uint8_t* sl = reinterpret_cast<uint8_t*>(base + L.sl + r0 * 4);
+        const unsigned s_stride = (unsigned)(L.rows * 4);
+        const long threads = (long)p.M * (p.K / 8);
+        hipLaunchKernelGGL(mx_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(p.A), p.lda, p.M, p.K,
+                           p.pro_lrelu, p.pro_slope, H, x4h, x4l, sh, sl, s_stride);
+        p.A = H; p.lda = p.K; p.pro_lrelu = 0;
+        p.mx_x4[0] = x4h; p.mx_x4[1] = x4l; p.mx_xs[0] = sh; p.mx_xs[1] = sl; p.mx_xs_stride = s_stride;
+    }
+    const int e = mx_epi_variant(p);
     switch (p.taps) {
-        case 3: launch_mx_taps<3>(p, s); break;
-        case 7: launch_mx_taps<7>(p, s); break;
-        default: launch_mx_taps<11>(p, s); break;
+        case 3: launch_mx_taps<3>(p, e, s); break;
+        case 7: launch_mx_taps<7>(p, e, s); break;
+        default: launch_mx_taps<11>(p, e, s); break;
     }
 }

@@ -39,13 +39,22 @@ struct ConvGemmParams {
                                                  // with the first two branches kept in fp16: half the traffic of acc32), or null
     int reserved1;
     // DT_MX only.  W_mx: the weight's fp4 planes (emotivoice_amd/mxfp4.py: pack_weight_planes), null -> the call runs as DT_F32S.
-    // mx_scratch: device scratch for the activation planes of this call, >= mx_scratch_bytes(M, K) bytes (ev_gemm_mx.h).
+    // Activations, either (a) A = fp32 [M][K] + mx_scratch (>= mx_scratch_bytes(M, K) bytes): the launcher first runs mx_planes_kernel
+    // (leaky-relu of pro_lrelu, then the planes) into the scratch, or (b) a plane set written by the producer's epilogue (mxo below):
+    // A = the fp16 hi plane (lda == K), mx_x4 / mx_xs / mx_xs_stride = its code and scale planes; pro_lrelu must be 0.
     const void* W_mx; void* mx_scratch; size_t mx_scratch_size;
-    // filled by the launcher (leave zero): fp4 code planes of the activations' hi / lo parts, their E8M0 scale planes
     const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int reserved2;
+    // Plane-set OUTPUT (any dtype whose launch takes an EPI_MXP epilogue: DT_MX kernels): besides / instead of out32 the epilogue writes
+    // the planes of a = lrelu(result, mxo_slope) (slope 1 = none) viewed as [rows][2^mxo_logC] (ldo == N; a transposed conv's
+    // [M][s * C] output is the [M * s][C] tensor): mxo_h fp16(a); mxo_q4[0] / [1] fp4 codes of fp16(a) and of a - fp16(a), C / 2 bytes
+    // per row; mxo_qs[0] / [1] their E8M0 block scales, one byte per 32 channels, chunk-major [C / 128][mxo_qs_stride / 4 rows][4].
+    // Invalid rows give all-zero planes.  Every plane needs 64 readable slack rows on both sides for its consumer.
+    void* mxo_h; void* mxo_q4[2]; void* mxo_qs[2]; unsigned mxo_qs_stride; int mxo_logC; float mxo_slope; int reserved3;
 };
 // bytes of activation-plane scratch a DT_MX call with an [M][K] input needs
 size_t mx_scratch_bytes(int M, int K);
+// 0 if the plane-set fields of a call are consistent with its dtype, shape and epilogue (launch_conv_gemm would run it)
+int mx_check(const ConvGemmParams& p);
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
 // per-device setup of the kernels in ev_gemm.hip (large-LDS opt-in, CU count of the persistent kernels); 0 = OK
 int init_device_kernels(int device);

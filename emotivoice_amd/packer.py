@@ -133,6 +133,22 @@ class _Blob:
         hi = w.astype(np.float16)
         self.add(name, ((w - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16), DT_F16)
 
+    def raw(self, name: str, data: np.ndarray):
+        """opaque bytes (the device code defines the layout), stored as an fp16-typed entry of ceil(n / 2) elements."""
+        d = np.ascontiguousarray(data, np.uint8).reshape(-1)
+        if d.size % 2:
+            d = np.concatenate([d, np.zeros(1, np.uint8)])
+        self.items.append((name, d.view(np.float16), DT_F16))
+
+    def mx(self, name: str, w: np.ndarray):
+        """fp4 planes of a GEMM-layout weight [N][taps][K] for the "mx" precision (mxfp4.pack_weight_planes), only for the shapes
+        conv_gemm_mx_kernel takes: N and K multiples of 128 and 3 / 7 / 11 taps.  The engine selects the MX kernel per layer by the
+        presence of this entry."""
+        N, taps, K = w.shape
+        if N % 128 == 0 and K % 128 == 0 and taps in (3, 7, 11):
+            from .mxfp4 import pack_weight_planes
+            self.raw(name, pack_weight_planes(w))
+
     def finish(self) -> Tuple[bytes, dict]:
         n = len(self.items)
         off = 16 + n * _ENTRY.size
@@ -245,6 +261,7 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
         wup = _convT_to_gemm(_fold_weight_norm(sd, f"{g}.ups.{i}"), u)
         b.add(f"voc.up{i}.w16", wup, DT_F16)
         b.lo(f"voc.up{i}.w16l", wup)
+        b.mx(f"voc.up{i}.wmx", wup)
         b.add(f"voc.up{i}.b", np.tile(f32(f"{g}.ups.{i}.bias"), u), DT_F32)
         ch //= 2
         for j in range(nk):
@@ -255,6 +272,7 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
                     wrb = _conv_to_gemm(_fold_weight_norm(sd, pre))
                     b.add(f"voc.rb{r}.{short}.{d}.w16", wrb, DT_F16)
                     b.lo(f"voc.rb{r}.{short}.{d}.w16l", wrb)
+                    b.mx(f"voc.rb{r}.{short}.{d}.wmx", wrb)
                     b.add(f"voc.rb{r}.{short}.{d}.b", f32(pre + ".bias"), DT_F32)
     wpost = _fold_weight_norm(sd, f"{g}.conv_post")     # [1, C, 7]
     b.add("voc.post.w", np.ascontiguousarray(wpost[0].T), DT_F32)   # [7][C]

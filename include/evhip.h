@@ -74,7 +74,10 @@ typedef struct ev_config {
                                    the handle's); 1: everything on the handle's stream.  The pitch / energy predictors use the same two streams beside the
                                    duration predictor. */
     int32_t vocoder_precision;  /* EV_PREC_F16 (default): fp16 operands / fp16 activations in HBM, fp32 accumulate;
-                                   EV_PREC_X3: fp32 activations, every product as three fp16 MFMAs on hi/lo splits (fp32-class accuracy) */
+                                   EV_PREC_X3: fp32 activations, every product as three fp16 MFMAs on hi/lo splits (fp32-class accuracy);
+                                   EV_PREC_MX: the X3 data flow, but layers with >= 128 channels evaluate a product as ONE fp16 MFMA
+                                   (hi x hi) + two block-scaled fp4 MFMAs for the cross terms (v_mfma_scale_f32_16x16x128_f8f6f4) on
+                                   operand planes written by the producing layer: waveform within ~4e-4 of the reference */
     int32_t reserved[4];
 } ev_config;
 
@@ -84,7 +87,7 @@ typedef struct ev_config {
  *      fp16 MFMAs with fp32 accumulation (2^-22 relative truncation: the fp32 rounding class at 1/3 of the fp16 rate).
  *      With decoder_precision = vocoder_precision = EV_PREC_X3 ("strict") the waveform matches the fp32 reference to ~1e-5
  *      relative L2 also on DC-free audio, where fp16 operands measure ~2e-3. */
-enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1, EV_PREC_X3 = 2 };
+enum { EV_PREC_F16 = 0, EV_PREC_F32 = 1, EV_PREC_X3 = 2, EV_PREC_MX = 3 };
 
 /* flags for ev_synthesize / ev_vocoder */
 enum {

@@ -582,3 +582,216 @@ def test_split_precision_8_wave_kernel_large_m(lib, C_, N, k, dil):
         # rows whose conv window stays inside the first `sub` rows see identical inputs in both launches
         assert torch.equal(big[:sub - h], small[:sub - h]), (C_, N, k, conv2)
         assert torch.isfinite(big).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "MX" precision: hi.hi as one fp16 MFMA + the two cross terms as block-scaled fp4 MFMAs (ev_gemm_mx.h).  emotivoice_amd/mxfp4.py
+# is the host statement of the plane format; the references below are built from it in fp64.
+def _mx_weights(w_nkt):
+    """w [N][K][taps] fp32 (cuda) -> dict of device tensors in the kernel's layouts + the dequantised fp4 parts (cpu fp64)."""
+    from emotivoice_amd import mxfp4
+    wg = w_nkt.permute(0, 2, 1).contiguous().float().cpu().numpy()            # [N][taps][K]
+    hi = wg.astype(np.float16)
+    lo = wg - hi.astype(np.float32)
+    planes = mxfp4.pack_weight_planes(wg)
+    qwl, qwh = mxfp4.weight_planes_dequant(planes, *wg.shape)
+    return dict(hi=torch.from_numpy(hi).cuda(), lo=torch.from_numpy((lo * np.float32(2048.0)).astype(np.float16)).cuda(),
+                mx=torch.from_numpy(planes).cuda(), wh=torch.from_numpy(hi.astype(np.float64)), qwl=torch.from_numpy(qwl.astype(np.float64)),
+                qwh=torch.from_numpy(qwh.astype(np.float64)), w=torch.from_numpy(wg.astype(np.float64)))
+
+
+def _mx_act_parts(a):
+    """a [rows][C] fp32 cpu -> (hi, Q(hi), Q(lo)) as fp64 + the planes as numpy (fp16 hi, codes hi / lo, scale bytes hi / lo)."""
+    from emotivoice_amd import mxfp4
+    an = a.numpy().astype(np.float32)
+    hi, lo = mxfp4.split_hi_lo(an)
+    ch, sh = mxfp4.quantize(hi, 32)
+    cl, sl = mxfp4.quantize(lo, 32)
+    t = lambda z: torch.from_numpy(np.asarray(z, np.float64))          # noqa: E731
+    return t(hi), t(mxfp4.dequantize(ch, sh, 32)), t(mxfp4.dequantize(cl, sl, 32)), (hi.astype(np.float16), ch, cl, sh, sl)
+
+
+def _conv64(x_rows, w_ntk, dil, taps):
+    """x [rows][K] fp64 (with halo rows), w [N][taps][K] fp64 -> valid conv [rows - (taps-1)*dil][N]."""
+    return F.conv1d(x_rows.t().unsqueeze(0), w_ntk.permute(0, 2, 1).contiguous(), dilation=dil).squeeze(0).t()
+
+
+class _PlaneSet:
+    """device plane set of an [M][C] activation with 64 slack rows on both sides (the layout ev_gemm_mx.h reads)."""
+
+    def __init__(self, M, Cc):
+        R = M + 2 * PAD
+        self.M, self.C, self.R = M, Cc, R
+        self.h = torch.full((R, Cc), 3.0, device="cuda", dtype=torch.float16)
+        self.q4 = [torch.full((R, Cc // 2), 0x77, device="cuda", dtype=torch.uint8) for _ in range(2)]
+        self.qs = [torch.full((Cc // 128, R, 4), 130, device="cuda", dtype=torch.uint8) for _ in range(2)]
+
+    def out_fields(self, d, slope):
+        d.mxo_h = self.h[PAD:].data_ptr()
+        d.mxo_q4[0], d.mxo_q4[1] = self.q4[0][PAD:].data_ptr(), self.q4[1][PAD:].data_ptr()
+        d.mxo_qs[0], d.mxo_qs[1] = self.qs[0][0, PAD:].data_ptr(), self.qs[1][0, PAD:].data_ptr()
+        d.mxo_qs_stride, d.mxo_logC, d.mxo_slope = self.R * 4, int(math.log2(self.C)), slope
+
+    def in_fields(self, d):
+        d.A, d.lda = self.h[PAD:].data_ptr(), self.C
+        d.mx_x4[0], d.mx_x4[1] = self.q4[0][PAD:].data_ptr(), self.q4[1][PAD:].data_ptr()
+        d.mx_xs[0], d.mx_xs[1] = self.qs[0][0, PAD:].data_ptr(), self.qs[1][0, PAD:].data_ptr()
+        d.mx_xs_stride = self.R * 4
+
+
+def _mx_desc(lib, wts, M, N, K, taps, dil, bias):
+    from emotivoice_amd import _ffi
+    d = _ffi.ev_conv_gemm_desc()
+    d.dtype, d.W, d.W_lo, d.W_mx = 3, wts["hi"].data_ptr(), wts["lo"].data_ptr(), wts["mx"].data_ptr()
+    d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), M, N, K, taps, dil, (taps - 1) // 2, 1.0
+    d.ldo = N
+    return d
+
+
+def _launch(lib, d):
+    torch.cuda.synchronize()
+    assert lib.ev_op_conv_gemm(C.byref(d), None) == 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("Cc,N,k,dil,M", [(128, 128, 3, 1, 512), (128, 128, 7, 3, 512), (128, 128, 11, 5, 768), (256, 256, 11, 1, 256),
+                                         (256, 1024, 3, 1, 256), (512, 2048, 3, 1, 256)])
+def test_mx_conv_gemm_fp32_input(lib, Cc, N, k, dil, M):
+    """DT_MX with an fp32 activation: mx_planes_kernel (leaky-relu, hi / lo split, fp4 planes) + conv_gemm_mx_kernel against the
+    fp64 evaluation of  xh.wh + Q(xh).Q(wl) + Q(xl).Q(wh)  with the host quantiser -- and against the exact product, which the
+    fp4 cross terms must approach to ~1e-4 (fp16 operands alone: 4e-4)."""
+    from emotivoice_amd import _ffi
+    torch.manual_seed(Cc + N + k)
+    full = torch.randn(M + 2 * PAD, Cc, device="cuda") * torch.exp(torch.randn(M + 2 * PAD, 1, device="cuda"))     # rows of very different scale
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x = full[PAD:PAD + M]
+    w = torch.randn(N, Cc, k, device="cuda") / math.sqrt(Cc * k)
+    bias = torch.randn(N, device="cuda")
+    wts = _mx_weights(w)
+    valid = torch.ones(M // 4, dtype=torch.uint8, device="cuda")
+    valid[:2] = 0
+    valid[50:53] = 0
+    vrow = valid.bool().repeat_interleave(4).cpu()
+    d = _mx_desc(lib, wts, M, N, Cc, k, dil, bias)
+    d.A, d.lda = x.data_ptr(), Cc
+    d.pro_lrelu, d.pro_slope, d.act, d.act_slope = 1, 0.1, 3, 0.1
+    d.row_valid, d.valid_shift = valid.data_ptr(), 2
+    nb = lib.ev_op_mx_scratch_bytes(M, Cc)
+    scratch = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    d.mx_scratch, d.mx_scratch_size = scratch.data_ptr(), nb
+    out = torch.full((M, N), 7.0, device="cuda")
+    d.out32 = out.data_ptr()
+    _launch(lib, d)
+    h = dil * (k - 1) // 2
+    a = _lrelu(full.float().cpu(), 0.1)
+    ah, qah, qal, _ = _mx_act_parts(a)
+    rows = slice(PAD - h, PAD + M + h)
+    emu = _conv64(ah[rows], wts["wh"], dil, k) + _conv64(qah[rows], wts["qwl"], dil, k) + _conv64(qal[rows], wts["qwh"], dil, k) + bias.double().cpu()
+    exact = _conv64(a.double()[rows], wts["w"], dil, k) + bias.double().cpu()
+    emu, exact = _lrelu(emu, 0.1), _lrelu(exact, 0.1)
+    emu[~vrow] = 0
+    exact[~vrow] = 0
+    got = out.cpu().double()
+    assert float(out[~vrow.cuda()].abs().max()) == 0.0
+    assert _rel(got, emu) < 2e-6, (Cc, N, k, _rel(got, emu))
+    assert _rel(got, exact) < 1.5e-4, (Cc, N, k, _rel(got, exact))
+    assert _rel(emu, exact) > 1e-6          # (the test would be vacuous if the emulation were exact)
+
+
+@pytest.mark.parametrize("Cc,k,dil,up", [(128, 7, 3, 0), (256, 3, 1, 0), (128, 11, 5, 0), (256, 3, 1, 4)])
+def test_mx_plane_set_chain(lib, Cc, k, dil, up):
+    """The producer's epilogue writes the consumer's operand planes (EPI_MXP): (1) the planes equal the host quantiser applied to
+    lrelu(out32) bit for bit (fp16 hi plane, fp4 codes, E8M0 scales, zero planes on invalid rows); (2) a second MX conv reading
+    them gives bit-identical results to the same conv fed with the fp32 tensor (planes made by mx_planes_kernel); (3) conv1-style
+    launches may write the planes ONLY; (4) up > 0: a transposed conv's [M][up * C] output lands as the [M * up][C] plane set;
+    (5) residual / accumulate-in epilogues with planes."""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(Cc * 7 + k + up)
+    M = 512
+    N1 = Cc * up if up else Cc                           # conv A: [M][Cc] -> [M][N1] (viewed as [M * max(up,1)][Cc])
+    M2 = M * up if up else M
+    full = torch.randn(M + 2 * PAD, Cc, device="cuda")
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    wa = torch.randn(N1, Cc, k, device="cuda") / math.sqrt(Cc * k)
+    ba = torch.randn(N1, device="cuda")
+    wtsa = _mx_weights(wa)
+    vshift = 2
+    valid = torch.ones(M >> vshift, dtype=torch.uint8, device="cuda")
+    valid[:3] = 0
+    valid[40:44] = 0
+    nb = lib.ev_op_mx_scratch_bytes(max(M, M2), Cc)
+    scratch = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    res = torch.randn(M, N1, device="cuda")
+    acc = torch.randn(M, N1, device="cuda")
+
+    def conv_a(with_out32, with_res):
+        ps = _PlaneSet(M2, Cc)
+        d = _mx_desc(lib, wtsa, M, N1, Cc, k, dil, ba)
+        d.A, d.lda, d.pro_lrelu, d.pro_slope = full[PAD:].data_ptr(), Cc, 1, 0.1
+        d.mx_scratch, d.mx_scratch_size = scratch.data_ptr(), nb
+        d.row_valid, d.valid_shift = valid.data_ptr(), vshift
+        out = torch.full((M, N1), 7.0, device="cuda") if with_out32 else None
+        if with_out32:
+            d.out32 = out.data_ptr()
+        if with_res:
+            d.res, d.res_dtype, d.ldres, d.out_scale = res.data_ptr(), 1, N1, 1.0 / 3.0
+            if with_res == 2:
+                d.acc32, d.ldacc = acc.data_ptr(), N1
+        else:
+            d.act, d.act_slope = 3, 0.1
+        ps.out_fields(d, 0.1 if with_res else 1.0)
+        _launch(lib, d)
+        return out, ps
+
+    def check_planes(out, ps, slope):
+        a = _lrelu(out.cpu().reshape(M2, Cc), slope)
+        _, _, _, (h16, ch, cl, sh, sl) = _mx_act_parts(a)
+        assert np.array_equal(ps.h[PAD:PAD + M2].cpu().numpy().view(np.uint16), h16.view(np.uint16)), "hi plane"
+        for i, (codes, sb) in enumerate(((ch, sh), (cl, sl))):
+            gs = ps.qs[i][:, PAD:PAD + M2].cpu().numpy()                      # [C/128][M2][4]
+            want = sb.reshape(M2, Cc // 128, 4).transpose(1, 0, 2)
+            bad = np.argwhere(gs != want)
+            assert bad.size == 0, ("scale plane %d" % i, bad[:4], gs[tuple(bad[0])], want[tuple(bad[0])])
+            gc = ps.q4[i][PAD:PAD + M2].cpu().numpy()
+            bad = np.argwhere(gc != codes)
+            assert bad.size == 0, ("code plane %d" % i, bad[:4], hex(gc[tuple(bad[0])]), hex(codes[tuple(bad[0])]))
+        vrow = valid.bool().repeat_interleave((1 << vshift) * max(up, 1)).cpu().numpy()
+        assert not ps.h[PAD:PAD + M2].cpu().numpy()[~vrow].any() and not ps.q4[0][PAD:PAD + M2].cpu().numpy()[~vrow].any()
+
+    out_a, ps_a = conv_a(True, 0)
+    check_planes(out_a, ps_a, 1.0)
+    _, ps_only = conv_a(False, 0)                                   # (3) planes only
+    assert torch.equal(ps_only.h, ps_a.h) and all(torch.equal(ps_only.q4[i][PAD:PAD + M2], ps_a.q4[i][PAD:PAD + M2]) for i in range(2))
+    assert all(torch.equal(ps_only.qs[i][:, PAD:PAD + M2], ps_a.qs[i][:, PAD:PAD + M2]) for i in range(2))
+    for mode in (1, 2):                                             # (5) residual (+ accumulate-in) epilogues, consumer slope 0.1
+        out_r, ps_r = conv_a(True, mode)
+        check_planes(out_r, ps_r, 0.1)
+    # (2) conv B on the plane set vs conv B on the fp32 tensor
+    wb = torch.randn(Cc, Cc, k, device="cuda") / math.sqrt(Cc * k)
+    bb = torch.randn(Cc, device="cuda")
+    wtsb = _mx_weights(wb)
+    # the planes' slack rows / the fp32 tensor's halo rows: zeros on both sides (what the engine's gap rows provide)
+    for t in [ps_a.h] + ps_a.q4:
+        t[:PAD] = 0
+        t[PAD + M2:] = 0
+    for t in ps_a.qs:
+        t[:, :PAD] = 1
+        t[:, PAD + M2:] = 1
+    fa = torch.zeros(M2 + 2 * PAD, Cc, device="cuda")
+    fa[PAD:PAD + M2] = out_a.reshape(M2, Cc)
+    outs = []
+    for planes_in in (True, False):
+        d = _mx_desc(lib, wtsb, M2, Cc, Cc, k, 1, bb)
+        if planes_in:
+            ps_a.in_fields(d)
+        else:
+            d.A, d.lda = fa[PAD:].data_ptr(), Cc                     # act = lrelu above, consumer slope 1: no prologue
+            d.mx_scratch, d.mx_scratch_size = scratch.data_ptr(), nb
+        o = torch.full((M2, Cc), 7.0, device="cuda")
+        d.out32 = o.data_ptr()
+        _launch(lib, d)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0]).all()
