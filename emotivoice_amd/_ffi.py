@@ -75,7 +75,8 @@ class ev_conv_gemm_desc(C.Structure):
 
 class ev_res_pair_desc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
-                ("M", C.c_int), ("k", C.c_int), ("dil", C.c_int), ("gmin", C.c_int), ("gmax", C.c_int), ("epi", ev_conv_gemm_desc)]
+                ("M", C.c_int), ("k", C.c_int), ("dil", C.c_int), ("gmin", C.c_int), ("gmax", C.c_int),
+                ("w1_mx", C.c_void_p), ("w2_mx", C.c_void_p), ("epi", ev_conv_gemm_desc)]
 
 
 # every symbol include/evhip.h and include/evhip_ops.h declare: (restype, argtypes)
@@ -106,6 +107,7 @@ SIGNATURES = {
     "ev_op_mx_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ev_op_resblock_pair_c32": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_resblock_pair_c64": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
+    "ev_op_resblock_pair_c32_mx": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_layernorm": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_float, _P, _P]),
     "ev_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
 }

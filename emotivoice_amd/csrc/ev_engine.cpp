@@ -511,7 +511,8 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
     const bool x3 = c.vocoder_precision == EV_PREC_X3 || mx;
     const size_t ves = x3 ? 4 : 2;
     auto set_out = [&](ConvGemmParams& q, void* dst) { if (x3) q.out32 = (float*)dst; else q.out16 = dst; };
-    auto has_mx = [&](const std::string& base) { return mx && h->wt.find(base + ".wmx") != h->wt.end(); };
+    auto has_wt = [&](const std::string& name) { return h->wt.find(name) != h->wt.end(); };
+    auto has_mx = [&](const std::string& base) { return mx && has_wt(base + ".wmx"); };
     bool prev_planes = false;           // vb.pl_nxt holds the plane set of lrelu(prev)
     ConvGemmParams p = gemm_defaults();
     if (voc_weights(h, "voc.pre", x3, p)) return -1;
@@ -607,7 +608,11 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                 const std::string c1 = rb + ".c1." + std::to_string(d), c2 = rb + ".c2." + std::to_string(d);
                 // fused pair kernels: C = 32 (every k) and C = 64 with k = 3 (the HBM-bound end of the generator; fp16 mode only)
                 const bool fused = !x3 && ((cout == 32 && (k == 3 || k == 7 || k == 11)) || (cout == 64 && k == 3)) && !getenv("EV_NO_FUSED_PAIR");
-                if (stage_mx) {
+                // EV_PREC_MX at C = 32: the whole pair in one persistent kernel (ev_pair_mx.h), x fp32 in, fp32 out
+                const bool fused_mx = mx && cout == 32 && (k == 3 || k == 7 || k == 11) && has_wt(c1 + ".wpmx") && has_wt(c2 + ".wpmx") &&
+                                      !getenv("EV_NO_FUSED_PAIR");
+                if (fused_mx) {
+                } else if (stage_mx) {
                     // MX stage: xt only ever exists as conv2's operand planes; x travels as fp32 (the residual) + the planes of lrelu(x)
                     const PlaneBuf& xin = d == 0 ? vb.pl_xu : ((d - 1) % 2 == 0 ? vb.pl_a : vb.pl_b);
                     p = gemm_defaults();
@@ -672,7 +677,17 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     (void)hipStreamWaitEvent(h->stream, h->ev_join[0], 0);
                     (void)hipStreamWaitEvent(h->stream, h->ev_join[1], 0);
                 }
-                if (fused) {
+                if (fused_mx) {
+                    WPTR(w1, char, c1 + ".w16"); WPTR(b1, float, c1 + ".b"); WPTR(w1m, char, c1 + ".wpmx"); WPTR(w2m, char, c2 + ".wpmx");
+                    ResPairParams rp;
+                    memset(&rp, 0, sizeof rp);
+                    rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = p.W; rp.w1_mx = w1m; rp.w2_mx = w2m;
+                    rp.M = p.M; rp.k = k; rp.dil = dil; rp.gmin = 0; rp.gmax = rows_out; rp.epi = p;
+                    const double fl = 2.0 * 2.0 * valid_out * cout * (double)cout * k;
+                    ConvGemmParams shape = p; shape.dil = dil;
+                    KScope ks(h, "voc_resblock_pair_c32_mx", fl, valid_out * cout * 4.0 * 2.0, sj, &shape);
+                    if (launch_resblock_pair_c32_mx(rp, sj)) return fail(h, "fused MX pair: unsupported call (k %d, dil %d)", k, dil);
+                } else if (fused) {
                     // conv1 -> LDS -> conv2 + residual / MRF epilogue in one persistent kernel (ev_gemm.hip)
                     WPTR(w1, char, c1 + ".w16"); WPTR(b1, float, c1 + ".b");
                     ResPairParams rp;
@@ -1479,6 +1494,13 @@ int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* stream) {
     if (p.k != 3 && p.k != 7 && p.k != 11) return -2;
     if (p.epi.post_lrelu && !(p.epi.post_slope >= 0.f && p.epi.post_slope <= 1.f)) return -2;   // max(v, s v) form of leaky-relu
     launch_resblock_pair_c32(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int ev_op_resblock_pair_c32_mx(const ev_res_pair_desc* d, void* stream) {
+    ResPairParams p;
+    memcpy(&p, d, sizeof p);
+    if (p.M <= 0 || p.dil < 1 || (p.k - 1) * p.dil > 64) return -2;
+    if (launch_resblock_pair_c32_mx(p, (hipStream_t)stream)) return -2;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int ev_op_resblock_pair_c64(const ev_res_pair_desc* d, void* stream) {

@@ -268,10 +268,10 @@ __device__ __forceinline__ unsigned mx_scale_byte(float amax) {
     const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 2;
     return (unsigned)min(max(e, 1), 254);
 }
-// One lane = 8 consecutive channels a[0..3] (packed pairs) at linear element offset `lin` of the [rows][C] tensor; the four lanes of a
-// 32-channel block (consecutive lanes, lane & 3 = position in the block) agree on the block maxima by two quad shuffles.  Writes 16 B of the
-// fp16 hi plane, 4 B of each code plane and (first lane of the block) one byte of each scale plane.
-__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, int lane) {
+// 8 consecutive channels a[0..3] (packed pairs) of one lane -> their share of the plane set: ho = the fp16 hi parts, ch / cl = the eight fp4
+// codes of the hi parts / of the fp32 remainders, bh / bl = the E8M0 scale bytes of the 32-channel block the lane belongs to.  The four
+// lanes of a block are consecutive (lane & 3 = position in the block) and agree on the block maxima by two quad shuffles.
+__device__ __forceinline__ void mx_quant8(const f32x2 (&a)[4], uint4& ho, unsigned& ch, unsigned& cl, unsigned& bh, unsigned& bl) {
     half2v hh[4];
     f32x2 hf[4], lf[4];
     float mh = 0.f, ml = 0.f;
@@ -285,16 +285,22 @@ __device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f3
     }
     mh = max_raw(mh, __shfl_xor(mh, 1)); mh = max_raw(mh, __shfl_xor(mh, 2));
     ml = max_raw(ml, __shfl_xor(ml, 1)); ml = max_raw(ml, __shfl_xor(ml, 2));
-    const unsigned bh = mx_scale_byte(mh), bl = mx_scale_byte(ml);
+    bh = mx_scale_byte(mh); bl = mx_scale_byte(ml);
     const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);       // the block scales as fp32 (2^(b - 127))
-    unsigned ch = 0, cl = 0;                                                           // v_cvt_scalef32_pk_fp4_f32: fp4(x / scale), RNE, saturating
+    ch = 0; cl = 0;                                                                    // v_cvt_scalef32_pk_fp4_f32: fp4(x / scale), RNE, saturating
     ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[0][0], hf[0][1], sh, 0); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[0][0], lf[0][1], sl, 0);
     ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[1][0], hf[1][1], sh, 1); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[1][0], lf[1][1], sl, 1);
     ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[2][0], hf[2][1], sh, 2); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[2][0], lf[2][1], sl, 2);
     ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[3][0], hf[3][1], sh, 3); cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[3][0], lf[3][1], sl, 3);
-    uint4 ho;
     ho.x = *reinterpret_cast<unsigned*>(&hh[0]); ho.y = *reinterpret_cast<unsigned*>(&hh[1]);
     ho.z = *reinterpret_cast<unsigned*>(&hh[2]); ho.w = *reinterpret_cast<unsigned*>(&hh[3]);
+}
+// One lane = 8 consecutive channels at linear element offset `lin` of the [rows][C] tensor: writes 16 B of the fp16 hi plane, 4 B of each
+// code plane and (first lane of the block) one byte of each scale plane.
+__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, int lane) {
+    uint4 ho;
+    unsigned ch, cl, bh, bl;
+    mx_quant8(a, ho, ch, cl, bh, bl);
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho;
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;
@@ -2232,6 +2238,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
 }
 
 #include "ev_gemm_mx.h"
+#include "ev_pair_mx.h"
 
 int init_device_kernels(int device) {
     if (device < 0 || device >= 64) return -1;
@@ -2252,9 +2259,30 @@ int init_device_kernels(int device) {
     if (x3_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (phased_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
+    if (pair_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     g_dev_ready[device] = (e == hipSuccess);
     return e == hipSuccess ? 0 : -1;
 }
+int launch_resblock_pair_c32_mx(const ResPairParams& p, hipStream_t s) {
+    const ConvGemmParams& e = p.epi;
+    if (!p.w1_mx || !p.w2_mx || !e.out32 || e.out16 || e.add16_a || e.post_lrelu || e.seq_bias || e.mxo_h || !(p.k == 3 || p.k == 7 || p.k == 11) ||
+        (p.k - 1) / 2 * (p.dil + 1) * 2 + 256 > 320 || p.ldx != 32) return -1;
+    const int n_cu = device_cus();
+    const int h2 = (p.k - 1) / 2, bmo = 256 - 2 * h2;
+    const int ntiles = (p.M + bmo - 1) / bmo;
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+#define EV_PMX_LAUNCH(KK)                                                                                                         \
+        if (e.acc32) hipLaunchKernelGGL((resblock_pair_c32_mx_kernel<KK, 1>), dim3(grid), dim3(512), PairMxGeom<KK>::TOTAL, s, p);   \
+        else hipLaunchKernelGGL((resblock_pair_c32_mx_kernel<KK, 0>), dim3(grid), dim3(512), PairMxGeom<KK>::TOTAL, s, p);
+    switch (p.k) {
+        case 3: EV_PMX_LAUNCH(3) break;
+        case 7: EV_PMX_LAUNCH(7) break;
+        default: EV_PMX_LAUNCH(11) break;
+    }
+#undef EV_PMX_LAUNCH
+    return 0;
+}
+
 void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s) {
     const size_t bytes = PAIR64_LDS_BYTES;
     const int n_cu = device_cus();

@@ -72,9 +72,13 @@ struct ResPairParams {
     int gmin, gmax;                     // rows g of x (relative to the x pointer) that exist in the tensor: gmin <= g < gmax.  {0, M} for a
                                         // whole tensor; a launch on a row sub-range (chunked execution) passes the tensor's real bounds so
                                         // that only true sequence edges are zero-padded.  gmax == 0 means {0, M}.
+    const void* w1_mx; const void* w2_mx;   // launch_resblock_pair_c32_mx only: the convs' fp4 planes (mxfp4.py: pack_pair_weight_planes)
     ConvGemmParams epi;
 };
 void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s);
+// the same pair in the MX arithmetic (ev_pair_mx.h): x / epi.res fp32 [rows][32], w1 / w2 the fp16 hi parts, w1_mx / w2_mx the fp4 planes;
+// epilogue: bias, fp32 residual (= x), out_scale, optional acc32, row mask, out32 only.  Returns 0, or -1 for an unsupported call.
+int launch_resblock_pair_c32_mx(const ResPairParams& p, hipStream_t s);
 // same pair at C = 64 (stage 2), k = 3 only: both weight sets (48 KB) stationary in LDS, x as two 64-byte K-chunk planes
 void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s);
 

@@ -103,3 +103,37 @@ def weight_planes_dequant(blob: np.ndarray, N: int, taps: int, K: int):
         sb = blob[2 * nc + i * ns: 2 * nc + (i + 1) * ns].reshape(N // 128, K // 128, taps, 128).transpose(0, 3, 2, 1).reshape(N, taps, K // 128)
         res.append(dequantize(codes, sb, W_SCALE_BLOCK))
     return res[0], res[1]
+
+
+def pack_pair_weight_planes(w: np.ndarray) -> np.ndarray:
+    """GEMM-layout weight [32][taps][32] fp32 of a C = 32 ResBlock conv -> the fp4 planes of the fused MX pair kernel (ev_pair_mx.h):
+         [Q(w - fp16(w)): KP x 32 x 16 B] [Q(fp16(w)): KP x 32 x 16 B] [scales of the first: KP x 32] [scales of the second: KP x 32]
+    tap-major ([tap][output channel]), one scale per (output channel, tap) = per 32 input channels = per MFMA k-block; the taps are
+    padded to KP = a multiple of four with zero codes (one v_mfma_scale_f32_16x16x128 covers four taps x 32 channels)."""
+    w = np.ascontiguousarray(w, np.float32)
+    N, taps, K = w.shape
+    assert N == 32 and K == 32, (N, K)
+    kp = (taps + 3) // 4 * 4
+    hi, lo = split_hi_lo(w)
+    codes, scales = [], []
+    for part in (lo, hi):
+        c, sb = quantize(part, 32)                           # [N][taps][16], [N][taps][1]
+        cp = np.zeros((kp, N, 16), np.uint8)
+        sp = np.ones((kp, N), np.uint8)
+        cp[:taps] = c.transpose(1, 0, 2)
+        sp[:taps] = sb[..., 0].T
+        codes.append(cp.reshape(-1))
+        scales.append(sp.reshape(-1))
+    return np.concatenate(codes + scales)
+
+
+def pair_weight_planes_dequant(blob: np.ndarray, taps: int):
+    """inverse of pack_pair_weight_planes (tests): -> (Q(wl), Q(wh)) as fp32 [32][taps][32]."""
+    kp = (taps + 3) // 4 * 4
+    nc, ns = kp * 32 * 16, kp * 32
+    res = []
+    for i in range(2):
+        c = blob[i * nc:(i + 1) * nc].reshape(kp, 32, 16)[:taps].transpose(1, 0, 2)
+        sb = blob[2 * nc + i * ns:2 * nc + (i + 1) * ns].reshape(kp, 32)[:taps].T[..., None]
+        res.append(dequantize(np.ascontiguousarray(c), np.ascontiguousarray(sb), 32))
+    return res[0], res[1]

@@ -149,6 +149,13 @@ class _Blob:
             from .mxfp4 import pack_weight_planes
             self.raw(name, pack_weight_planes(w))
 
+    def mx_pair(self, name: str, w: np.ndarray):
+        """fp4 planes of a C = 32 ResBlock conv for the fused MX pair kernel (mxfp4.pack_pair_weight_planes)."""
+        N, taps, K = w.shape
+        if N == 32 and K == 32 and taps in (3, 7, 11):
+            from .mxfp4 import pack_pair_weight_planes
+            self.raw(name, pack_pair_weight_planes(w))
+
     def finish(self) -> Tuple[bytes, dict]:
         n = len(self.items)
         off = 16 + n * _ENTRY.size
@@ -273,6 +280,7 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
                     b.add(f"voc.rb{r}.{short}.{d}.w16", wrb, DT_F16)
                     b.lo(f"voc.rb{r}.{short}.{d}.w16l", wrb)
                     b.mx(f"voc.rb{r}.{short}.{d}.wmx", wrb)
+                    b.mx_pair(f"voc.rb{r}.{short}.{d}.wpmx", wrb)
                     b.add(f"voc.rb{r}.{short}.{d}.b", f32(pre + ".bias"), DT_F32)
     wpost = _fold_weight_norm(sd, f"{g}.conv_post")     # [1, C, 7]
     b.add("voc.post.w", np.ascontiguousarray(wpost[0].T), DT_F32)   # [7][C]

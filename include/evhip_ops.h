@@ -64,9 +64,14 @@ typedef struct ev_res_pair_desc {
     const void* w2;
     int M, k, dil;
     int gmin, gmax;    /* rows of x that exist (relative to x): gmin <= g < gmax; leave both 0 for the whole tensor {0, M} */
+    const void* w1_mx; const void* w2_mx;   /* ev_op_resblock_pair_c32_mx only: mxfp4.pack_pair_weight_planes(w) of the two convs */
     ev_conv_gemm_desc epi;
 } ev_res_pair_desc;
 int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* hip_stream);
+/* The same pair in the MX arithmetic (one fp16 MFMA + two block-scaled fp4 MFMAs per product): x and out32 fp32 [rows][32], w1 / w2 the
+ * fp16 hi parts of the weights, w1_mx / w2_mx their fp4 planes; epi: bias, res (= x, fp32), row_valid, out_scale, acc32 (optional, may
+ * alias out32), out32, ldo. */
+int ev_op_resblock_pair_c32_mx(const ev_res_pair_desc* d, void* hip_stream);
 /* the same pair at C = 64 (HiFi-GAN stage 2), k = 3 only (both weight sets stay in LDS) */
 int ev_op_resblock_pair_c64(const ev_res_pair_desc* d, void* hip_stream);
 

@@ -795,3 +795,77 @@ def test_mx_plane_set_chain(lib, Cc, k, dil, up):
         outs.append(o)
     assert torch.equal(outs[0], outs[1])
     assert torch.isfinite(outs[0]).all()
+
+
+@pytest.mark.parametrize("k,dil,acc_in", [(3, 1, False), (3, 5, True), (7, 3, False), (7, 1, True), (11, 5, True), (11, 1, False)])
+def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
+    """resblock_pair_c32_mx_kernel (ev_pair_mx.h): conv1(dil) -> leaky-relu -> conv2 + fp32 residual, every product as one fp16 MFMA +
+    two fp4 MFMAs (four taps per instruction), x fp32 in / fp32 out, the slab and the intermediate quantised in the kernel.  References in
+    fp64: (a) the same arithmetic with the host quantiser (mxfp4.py) -- tight; (b) the exact convs of models/hifigan/models.py:50-57 -- the
+    MX error level (~1e-4; fp16 operands give 5e-4)."""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(300 + k + dil)
+    Cc, M = 32, 5 * 256
+    full = torch.randn(M + 2 * PAD, Cc, device="cuda") * torch.exp(0.7 * torch.randn(M + 2 * PAD, 1, device="cuda"))
+    valid = torch.ones(M // 16, dtype=torch.uint8, device="cuda")
+    valid[:2] = 0
+    valid[30:34] = 0
+    valid[-3:] = 0
+    vrow = valid.repeat_interleave(16).bool()
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x = full[PAD:PAD + M]
+    x[~vrow] = 0                                   # the engine's invariant: invalid rows of every tensor are exact zeros
+    w1 = torch.randn(Cc, Cc, k, device="cuda") / math.sqrt(Cc * k)
+    w2 = torch.randn(Cc, Cc, k, device="cuda") / math.sqrt(Cc * k)
+    b1, b2 = torch.randn(Cc, device="cuda") * 0.1, torch.randn(Cc, device="cuda") * 0.1
+    acc = torch.randn(M, Cc, device="cuda")
+
+    def wparts(w):
+        wg = w.permute(0, 2, 1).contiguous().cpu().numpy()            # [N][taps][K]
+        planes = mxfp4.pack_pair_weight_planes(wg)
+        ql, qh = mxfp4.pair_weight_planes_dequant(planes, k)
+        hi = wg.astype(np.float16)
+        t = lambda z: torch.from_numpy(np.asarray(z, np.float64))      # noqa: E731
+        return torch.from_numpy(hi).cuda(), torch.from_numpy(planes).cuda(), t(hi), t(ql), t(qh), t(wg)
+    w1h, w1m, w1hd, w1ql, w1qh, w1e = wparts(w1)
+    w2h, w2m, w2hd, w2ql, w2qh, w2e = wparts(w2)
+    out = acc.clone() if acc_in else torch.full((M, Cc), 7.0, device="cuda")
+    d = _ffi.ev_res_pair_desc()
+    d.x, d.ldx, d.w1, d.b1, d.w2, d.M, d.k, d.dil = x.data_ptr(), Cc, w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), M, k, dil
+    d.w1_mx, d.w2_mx = w1m.data_ptr(), w2m.data_ptr()
+    e = d.epi
+    e.bias, e.res, e.res_dtype, e.ldres = b2.data_ptr(), x.data_ptr(), 1, Cc
+    e.row_valid, e.valid_shift, e.out_scale = valid.data_ptr(), 4, 1.0 / 3.0
+    if acc_in:
+        e.acc32, e.ldacc = out.data_ptr(), Cc       # in place: the engine's running MRF sum
+    e.out32, e.ldo = out.data_ptr(), Cc
+    torch.cuda.synchronize()
+    assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
+    torch.cuda.synchronize()
+    h = (k - 1) // 2
+
+    def mxconv(a_rows, whd, wql, wqh, dd):
+        ah, qah, qal, _ = _mx_act_parts(a_rows.float())
+        return _conv64(ah, whd, dd, k) + _conv64(qah, wql, dd, k) + _conv64(qal, wqh, dd, k)
+    xin = full.cpu()
+    a0 = _lrelu(xin, 0.1)
+    vr = vrow.cpu()
+    # conv1 on rows [-h, M + h) of the tensor (it needs h * dil more on each side), masked to the valid rows
+    r1 = slice(PAD - h - h * dil, PAD + M + h + h * dil)
+    vmask1 = torch.zeros(M + 2 * h, dtype=torch.bool)
+    vmask1[h:h + M] = vr
+    addend = acc.double().cpu() if acc_in else 0.0
+    res = {}
+    for name, conv in (("emu", lambda a, i, dd: mxconv(a, *((w1hd, w1ql, w1qh) if i == 0 else (w2hd, w2ql, w2qh)), dd)),
+                       ("exact", lambda a, i, dd: _conv64(a.double(), w1e if i == 0 else w2e, dd, k))):
+        xt = _lrelu(conv(a0[r1], 0, dil) + b1.double().cpu(), 0.1)
+        xt[~vmask1] = 0
+        y = (conv(xt.float() if name == "emu" else xt, 1, 1) + b2.double().cpu() + xin[PAD:PAD + M].double()) / 3.0 + addend
+        y[~vr] = 0
+        res[name] = y
+    got = out.cpu().double()
+    assert float(out[~vrow].abs().max()) == 0.0
+    assert _rel(got, res["emu"]) < 1e-5, (k, dil, _rel(got, res["emu"]))
+    assert _rel(got, res["exact"]) < 2e-4, (k, dil, _rel(got, res["exact"]))
+    assert _rel(res["emu"], res["exact"]) > 1e-6

@@ -61,6 +61,8 @@ def test_blob_table_and_manifest(packed):
     assert t["voc.up0.w16"].shape == (8 * 256, 3, 512) and t["voc.up3.w16"].shape == (2 * 32, 3, 64)
     assert t["voc.rb11.c2.2.w16"].shape == (32, 11, 32) and t["voc.post.w"].shape == (7, 32)
     for k, v in t.items():
+        if k.endswith(".wmx") or k.endswith(".wpmx"):
+            continue                                   # opaque fp4 planes stored under an fp16-typed entry (test_mx_weight_planes)
         assert np.isfinite(v.astype(np.float32)).all(), k
 
 
@@ -125,7 +127,7 @@ def test_legacy_weight_g_v_keys_and_module_prefix(packed):
     blob2, _ = packer.pack_state_dict(legacy, pe_len=512)
     t2 = parse_blob(blob2)
     for k in t:
-        assert np.array_equal(t[k], t2[k]), k
+        assert t[k].tobytes() == t2[k].tobytes(), k          # (bytes: the fp4 planes are not numbers)
 
 
 def test_missing_key_raises(packed):
@@ -133,3 +135,30 @@ def test_missing_key_raises(packed):
     del sd["am.to_mel.bias"]
     with pytest.raises(KeyError):
         packer.pack_state_dict(sd, pe_len=64)
+
+
+def test_mx_weight_planes(packed):
+    """The "mx" precision's fp4 planes: present exactly for the generator convs the MX kernels take (N, K % 128 == 0: stages 0-1 and their
+    up-convs; C = 32: the fused pair kernel), bytes = mxfp4's packers applied to the folded fp32 weight, and the dequantised planes
+    reproduce lo = w - fp16(w) and hi = fp16(w) to fp4 accuracy (relative L2 ~0.1: two significant bits)."""
+    from emotivoice_amd import mxfp4
+    sd, tsd, t, man = packed
+    mx = sorted(k for k in t if k.endswith(".wmx"))
+    pmx = sorted(k for k in t if k.endswith(".wpmx"))
+    assert [k for k in mx if ".up" in k] == ["voc.up0.wmx", "voc.up1.wmx", "voc.up2.wmx"]
+    assert len([k for k in mx if ".rb" in k]) == 2 * 3 * 3 * 2 and all(int(k.split(".")[1][2:]) < 6 for k in mx if ".rb" in k)
+    assert len(pmx) == 3 * 3 * 2 and all(int(k.split(".")[1][2:]) >= 9 for k in pmx)
+    for name, shape in (("voc.rb0.c1.1", (256, 3, 256)), ("voc.rb5.c2.0", (128, 11, 128)), ("voc.up1", (1024, 3, 256))):
+        w16 = t[name + ".w16"].astype(np.float32)
+        lo = t[name + ".w16l"].astype(np.float32) / 2048.0
+        w = w16 + lo                                                        # the folded fp32 weight up to 2^-22
+        assert w16.shape == shape
+        blob = t[name + ".wmx"].view(np.uint8)
+        want = mxfp4.pack_weight_planes(w)
+        assert blob.size in (want.size, want.size + 1)
+        ql, qh = mxfp4.weight_planes_dequant(blob[:want.size], *shape)
+        assert np.linalg.norm(qh - w16) / np.linalg.norm(w16) < 0.2
+        assert np.linalg.norm(ql - lo) / np.linalg.norm(lo) < 0.25
+    w16 = t["voc.rb11.c1.2.w16"].astype(np.float32)
+    ql, qh = mxfp4.pair_weight_planes_dequant(t["voc.rb11.c1.2.wpmx"].view(np.uint8), 11)
+    assert np.linalg.norm(qh - w16) / np.linalg.norm(w16) < 0.2 and ql.shape == (32, 11, 32)
