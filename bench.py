@@ -39,6 +39,12 @@ VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0                                  # GB/s
+DTYPE_NAME = {"f16": "f16", "x3": "f16x3 (fp16 hi/lo split, 3 MFMAs per product, fp32 activations)",
+              "mx": "f16+mxfp4 (fp32 activations; per product one fp16 MFMA on the hi parts + two block-scaled fp4 MFMAs for the cross terms; "
+                    "split-precision fp16x3 where channels < 128 and in the mel decoder)"}
+# measured DC-free relative L2 of the waveform against the reference's own outputs (tests/test_gpu_parity.py, profiles/r3_*_parity_report.json)
+PARITY_LEVEL = {"mx": "<= 3.2e-4 on every fixture incl. zero-mean (bar 1e-3)", "fast": "2.4e-3 on zero-mean audio (bar 1e-3: NOT met)",
+                "strict": "<= 3e-6"}
 REFERENCE_CPU_FRAMES_PER_S = 628.0                 # the reference's own JETSGenerator, 8 Xeon cores, B = 1, N = 256
 
 
@@ -149,64 +155,82 @@ def timed(work, steps, warmup, sync):
     return frames, time.perf_counter() - t0
 
 
-def roofline_block(eng, work, torch, strict):
-    """One extra profiled step (hipEvents on the engine's stream around every launch, single stream) -> per-family accounting."""
+# kernel families of the generator per precision mode: (stat name, MFMA-equivalents issued per algorithmic product, description)
+VOC_FAMILIES = {
+    "voc_conv_gemm_f16": (1.0, "conv_gemm_kernel<f16> + conv_gemm_phased_kernel: one fp16 MFMA per product"),
+    "voc_resblock_pair_c32": (1.0, "resblock_pair_c32_kernel (fused pair, fp16)"),
+    "voc_resblock_pair_c64": (1.0, "resblock_pair_c64_kernel (fused pair, fp16)"),
+    "voc_conv_gemm_x3": (3.0, "conv_gemm_x3_kernel / conv_gemm_split_kernel: three fp16 MFMAs per product"),
+    "voc_conv_gemm_mx": (1.5, "conv_gemm_mx_kernel: one fp16 MFMA + two block-scaled fp4 MFMAs (4x rate) per product, operand planes from the producer's epilogue"),
+    "voc_resblock_pair_c32_mx": (1.5, "resblock_pair_c32_mx_kernel (fused pair, fp16 + fp4 MFMAs, fp32 in / out)"),
+}
+DOMINANT = {"f16": "voc_conv_gemm_f16", "x3": "voc_conv_gemm_x3", "mx": "voc_conv_gemm_mx"}
+
+
+def roofline_block(eng, work, torch, strict=None):
+    """One extra profiled step (hipEvents on the engine's stream around every launch, single stream) -> per-family accounting.
+    `achieved` of the dominant family = the ALGORITHMIC FLOPs of exactly its launches (one product per multiply-add, transposed convs at
+    their two real taps) / the sum of their hipEvent durations; `issued_equiv_*` scales that by the MFMA-equivalents the family's
+    arithmetic issues per product (3 for the split precision, 1.5 for MX: the fp4 MFMA runs at 4x the fp16 rate)."""
     eng.set_profiling(True)
     res = work.calls[0]()
     torch.cuda.synchronize()
     stats = {s["name"]: s for s in eng.kernel_stats()}
     stages = eng.timings()
+    mode = eng.vocoder_precision
     dump = os.environ.get("EV_DUMP_LAUNCHES")             # per-launch table (kernel, shape, ms, TF/s, GB/s) for profiles/
     if dump:
         recs = eng.launch_records()
         for r in recs:
             r["TFLOPs"] = round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["ms"] > 0 and r["flops"] > 0 else None
             r["GBps"] = round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 and r["bytes"] > 0 else None
-        with open(dump + (".strict" if strict else ""), "w") as f:
+        with open(dump + ("" if mode == "f16" else "." + mode), "w") as f:
             json.dump(recs, f, indent=0)
     eng.set_profiling(False)
     f1 = int(res.total_frames)
     B = int(res.batch)
     kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in stats.items()}
-    voc = stats.get("voc_conv_gemm_x3" if strict else "voc_conv_gemm_f16")
+    dom = stats.get(DOMINANT[mode])
     roof = None
-    if voc and voc["ms"] > 0:
-        pair = stats.get("voc_resblock_pair_c32")
-        pair64 = stats.get("voc_resblock_pair_c64")
-        # algorithmic FLOPs of what THIS kernel family executed: all generator convs minus the ResBlocks that ran in the
-        # fused pair kernels (fast mode: stage 3, and the k = 3 ResBlock of stage 2)
-        gemm_flop = VOC_CONV_FLOP_PER_FRAME - (VOC_STAGE3_RB_FLOP_PER_FRAME if pair else 0.0) - (VOC_STAGE2_K3_RB_FLOP_PER_FRAME if pair64 else 0.0)
-        achieved = gemm_flop * f1 / (voc["ms"] * 1e-3) / 1e12
-        voc_ms = voc["ms"] + (pair["ms"] if pair else 0.0) + (pair64["ms"] if pair64 else 0.0)
-        traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
+    if dom and dom["ms"] > 0:
+        units, desc = VOC_FAMILIES[DOMINANT[mode]]
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        fams = {}
+        voc_ms = voc_issued = 0.0
+        for name, (u, d) in VOC_FAMILIES.items():
+            st = stats.get(name)
+            if not st or st["ms"] <= 0:
+                continue
+            tf = st["flops"] / (st["ms"] * 1e-3) / 1e12
+            fams[name] = dict(ms=round(st["ms"], 3), launches=st["launches"], algorithmic_TFLOPs=round(tf, 2), mfma_units_per_product=u,
+                              issued_equiv_frac=round(u * tf / PEAK_MFMA_F16, 4))
+            voc_ms += st["ms"]
+            voc_issued += u * st["flops"]
+        traffic = tnote = None      # HBM bytes per launch of the dominant family from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
         tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
-        if os.path.exists(tpath) and not strict and work.mode == "am_vocoder" and B == 32:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        name = ("conv_gemm_x3_kernel (split precision: 3 fp16 MFMAs per algorithmic product; every HiFi-GAN Conv1d/ConvTranspose1d)" if strict else
-                "conv_gemm_kernel<f16> + conv_gemm_phased_kernel (HiFi-GAN Conv1d/ConvTranspose1d: conv_pre, ups, ResBlocks of stages 0-2 except the fused k=3 one)")
-        roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=PEAK_MFMA_F16, unit="TFLOP/s",
-                    frac=round(achieved / PEAK_MFMA_F16, 4), traffic=traffic,
-                    traffic_note="HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json",
-                    launches=voc["launches"], avg_launch_ms=round(voc["ms"] / voc["launches"], 4),
-                    algorithmic_flop_per_launch=round(gemm_flop * f1 / voc["launches"], 1),
+        if os.path.exists(tpath) and work.mode == "am_vocoder" and B == 32:
+            t = json.load(open(tpath))
+            t = t.get(mode, t if mode == "f16" and "hbm_bytes_per_launch" in t else {})
+            traffic = t.get("hbm_bytes_per_launch")
+            tnote = "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json"
+        roof = dict(bound="mfma", kernel=desc + " (HiFi-GAN Conv1d / ConvTranspose1d launches of this family)",
+                    achieved=round(achieved, 2), peak=PEAK_MFMA_F16, unit="TFLOP/s", frac=round(achieved / PEAK_MFMA_F16, 4),
+                    traffic=traffic, traffic_note=tnote, launches=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+                    algorithmic_flop_per_launch=round(dom["flops"] / dom["launches"], 1),
+                    mfma_units_per_product=units, issued_equiv_TFLOPs=round(units * achieved, 2), issued_equiv_frac=round(units * achieved / PEAK_MFMA_F16, 4),
+                    note="achieved / frac count ALGORITHMIC FLOPs; issued_equiv_* = what the matrix pipes execute in fp16-MFMA equivalents",
+                    families=fams,
                     all_vocoder_convs=dict(ms=round(voc_ms, 3), mfma_TFLOPs=round(VOC_CONV_FLOP_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e12, 2),
+                                           issued_equiv_frac=round(voc_issued / (voc_ms * 1e-3) / 1e12 / PEAK_MFMA_F16, 4),
                                            hbm_contract_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9, 1),
-                                           hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4)))
-        if strict:
-            roof["mfma_issued_TFLOPs"] = round(3.0 * achieved, 2)      # what the matrix pipes execute: three MFMAs per product
-            roof["mfma_issued_frac"] = round(3.0 * achieved / PEAK_MFMA_F16, 4)
-            roof["note"] = "achieved / frac count ALGORITHMIC FLOPs (one product per multiply-add); the split-precision arithmetic issues 3x that on the fp16 matrix pipes (mfma_issued_*)"
-        if pair:
-            roof["fused_pair_kernel"] = dict(ms=round(pair["ms"], 3), launches=pair["launches"],
-                                             mfma_TFLOPs=round(VOC_STAGE3_RB_FLOP_PER_FRAME * f1 / (pair["ms"] * 1e-3) / 1e12, 2))
-        if pair64:
-            roof["fused_pair_kernel_c64"] = dict(ms=round(pair64["ms"], 3), launches=pair64["launches"],
-                                                 mfma_TFLOPs=round(VOC_STAGE2_K3_RB_FLOP_PER_FRAME * f1 / (pair64["ms"] * 1e-3) / 1e12, 2))
+                                           hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
+                                           hbm_contract_note="the layer-wise fp16 contract (2.026 MB / frame); fp32-class modes move 2x that layer-wise"))
     if roof is not None and "decoder" in stages and stages["decoder"] > 0:
         dflop = decoder_flops(f1 / max(B, 1)) * B if work.mode == "am_vocoder" else None
         if dflop:
             tf = dflop / (stages["decoder"] * 1e-3) / 1e12
-            roof["mel_decoder"] = dict(ms=round(stages["decoder"], 3), mfma_TFLOPs=round(tf, 2), mfma_frac=round(tf / PEAK_MFMA_F16, 4))
+            roof["mel_decoder"] = dict(ms=round(stages["decoder"], 3), mfma_TFLOPs=round(tf, 2), mfma_frac=round(tf / PEAK_MFMA_F16, 4),
+                                       precision=eng.decoder_precision)
     return roof, stages, kernels
 
 
@@ -296,11 +320,12 @@ def main():
     ap.add_argument("--sub-batches", type=int, default=0, help="am_vocoder: sub-batches per step (default 1 at N = 1, 8 at N > 1 = configs[3])")
     ap.add_argument("--phonemes", type=int, default=256)
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances for the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", default="fast", choices=["fast", "strict", "mx"],
-                    help="frame-rate path: fast = fp16 MFMA operands (BASELINE configs: bf16 / fp16); strict = split precision "
-                         "(3 fp16 MFMAs per product, fp32 activations)")
+    ap.add_argument("--precision", default="mx", choices=["mx", "fast", "strict"],
+                    help="frame-rate path: mx (default, the contract mode: waveform <= 1e-3 on every fixture) = fp32 activations, one fp16 MFMA + "
+                         "two block-scaled fp4 MFMAs per product; fast = fp16 MFMA operands / fp16 activations (2.4e-3 on zero-mean audio); "
+                         "strict = split precision (3 fp16 MFMAs per product, ~1e-6)")
     ap.add_argument("--decoder-precision", default=None, choices=["f16", "f32", "x3"])
-    ap.add_argument("--no-other-precision", action="store_true", help="skip the extra timed pass in the other precision (N = 1)")
+    ap.add_argument("--no-other-precision", action="store_true", help="skip the extra timed passes in the other precisions (N = 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: put every rank on this device (with --backend gloo)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -379,8 +404,7 @@ def main():
 
     roof, stages, kernels, lat, other = None, {}, {}, {}, None
     if rank == 0:
-        strict = eng.vocoder_precision in ("x3", "mx")
-        roof, stages, kernels = roofline_block(eng, work, torch, strict)
+        roof, stages, kernels = roofline_block(eng, work, torch)
         # single-utterance latency (the reference's own call pattern, B = 1; BASELINE configs[0] is 64 phonemes): host-to-host
         # wall time of one ev_synthesize with host inputs, best of 20
         if args.mode == "am_vocoder":
@@ -398,18 +422,20 @@ def main():
                         best = min(best, dtl)
                 lat["b1_%dph_ms" % nph] = round(best * 1e3, 3)
                 lat["b1_%dph_x_realtime" % nph] = round(int(r1.total_frames) * 256 / 16000 / best, 1)
-        # the same workload in the other precision (one engine at a time: the first one's workspace is released first)
+        # the same workload in the other precisions (one engine at a time: the previous one's workspace is released first)
         if world == 1 and not args.no_other_precision and args.decoder_precision is None:
             eng.close()
-            op = "strict" if args.precision == "fast" else "fast"
-            eng2 = make_engine(op)
-            work2 = Workload(args, eng2, rank, dev, torch, _ffi)
-            f2, dt2 = timed(work2, max(3, args.steps // 2), 2, lambda: torch.cuda.synchronize())
-            roof2, stages2, _ = roofline_block(eng2, work2, torch, op == "strict")
-            other = dict(precision=op, value=round(f2 / dt2, 1), unit="mel-frames/s", x_realtime=round(f2 / dt2 * 256 / 16000, 1),
-                         ms_per_step=round(dt2 / max(3, args.steps // 2) * 1e3, 3), roofline=roof2,
-                         stage_ms={k: round(v, 3) for k, v in stages2.items()})
-            eng2.close()
+            other = []
+            for op in [m for m in ("mx", "fast", "strict") if m != args.precision]:
+                eng2 = make_engine(op)
+                work2 = Workload(args, eng2, rank, dev, torch, _ffi)
+                n2 = max(3, args.steps // 2)
+                f2, dt2 = timed(work2, n2, 2, lambda: torch.cuda.synchronize())
+                roof2, stages2, _ = roofline_block(eng2, work2, torch)
+                other.append(dict(precision=op, waveform_rel_l2_vs_reference=PARITY_LEVEL[op], value=round(f2 / dt2, 1), unit="mel-frames/s",
+                                  x_realtime=round(f2 / dt2 * 256 / 16000, 1), ms_per_step=round(dt2 / n2 * 1e3, 3), roofline=roof2,
+                                  stage_ms={k: round(v, 3) for k, v in stages2.items()}))
+                eng2.close()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -417,7 +443,6 @@ def main():
 
     sr, hop = 16000, 256
     value = frames / dt
-    fast = (eng.decoder_precision, eng.vocoder_precision) == ("f16", "f16")
     cfg = dict(work.desc)
     cfg.update(global_batch=work.utts_per_step * world, parallelism="utterance-sharded x%d" % world, precision=args.precision,
                token_rate_precision="f32 (split fp16x3 GEMMs)", frame_rate_precision="%s/%s" % (eng.decoder_precision, eng.vocoder_precision))
@@ -426,7 +451,7 @@ def main():
         "x_realtime": round(value * hop / sr, 1),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if fast else "f16x3 (fp16 hi/lo split, 3 MFMAs per product, fp32 activations)",
+        "dtype": DTYPE_NAME[eng.vocoder_precision], "precision": args.precision, "waveform_rel_l2_vs_reference": PARITY_LEVEL[args.precision],
         "data": "synthetic", "ranks_seen": ranks_seen, "config": cfg,
         "latency": lat, "roofline": roof, "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "kernels_ms": kernels,
         "other_precision": other,

@@ -315,10 +315,11 @@ int check_gemm(ev_handle* h, const ConvGemmParams& p) {
     if (mx_check(p)) return fail(h, "gemm: inconsistent MX plane-set fields (dtype %d, N %d, K %d, taps %d)", p.dtype, p.N, p.K, p.taps);
     return 0;
 }
-int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_rows, hipStream_t st = nullptr) {
+// flop_scale: algorithmic / executed FLOPs (2/3 for a ConvTranspose1d run as a 3-tap conv: each output sample has two real taps)
+int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_rows, hipStream_t st = nullptr, double flop_scale = 1.0) {
     if (check_gemm(h, p)) return -1;
     const int es = p.dtype == DT_F16 ? 2 : 4;
-    const double flops = 2.0 * valid_rows * p.N * (double)p.K * p.taps;
+    const double flops = 2.0 * valid_rows * p.N * (double)p.K * p.taps * flop_scale;
     double bytes = valid_rows * ((double)p.K * es + (double)p.N * (p.out16 ? 2 : 0) + (double)p.N * (p.out32 ? 4 : 0)) +
                    (double)p.N * p.K * p.taps * es;
     KScope ks(h, name, flops, bytes, st, &p);
@@ -548,7 +549,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         }
         if (p.dtype == DT_MX && stage_mx) mx_out(p, mx_view(vb.pl_xu, (size_t)rows_out, cout), 0.1f);      // lrelu(x) of models.py:51, shared by the three ResBlocks
         else stage_mx = false;
-        if (gemm(h, p.dtype == DT_MX ? "voc_conv_gemm_mx" : gname, p, valid_in)) return -1;
+        if (gemm(h, p.dtype == DT_MX ? "voc_conv_gemm_mx" : gname, p, valid_in, nullptr, 2.0 / 3.0)) return -1;
         const bool next_up_mx = stage_mx && i + 1 < c.n_up && has_mx("voc.up" + std::to_string(i + 1));
         U *= s;
         const int shift = ilog2(U);
