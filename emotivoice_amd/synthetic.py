@@ -21,6 +21,7 @@ Duration-head calibration:
 A "_zdc" suffix (e.g. "parity_zdc") additionally sets conv_post's bias to ZDC_POST_BIAS, the value at which the
 synthetic generator's waveform is (nearly) zero-mean like real audio: the plain weights give a waveform whose DC
 offset is ~3x its AC amplitude, which flatters every relative-L2 figure by that factor.
+A further "_hot" suffix ("parity_zdc_hot") switches the generator to trained-like gains (see HOT_* below).
 """
 from __future__ import annotations
 
@@ -34,6 +35,13 @@ from .config import EVShapes  # noqa: E402
 
 
 ZDC_POST_BIAS = -0.5253      # waveform mean within +-0.03 of zero (std 0.2) over seeded utterances (bisection on the oracle)
+# "_hot" weights (trained-like dynamic range, SURVEY section 8(c) / VERDICT r2 #7): larger weight-norm gains in the generator so that
+# the stage activations climb from O(1) at conv_pre to 10^2..10^3 at the last stage (released HiFi-GAN checkpoints have this kind
+# of growth; N(0, 0.01)-like weights keep everything O(1) and never stress fp16 storage), conv_post scaled back so that tanh is
+# not saturated, and its bias re-centred for a zero-mean waveform (tools/calibrate_hot.py prints these three numbers).
+HOT_VOC_GAIN, HOT_RB_GAIN = 2.2, 3.0
+HOT_POST_GAIN = 0.00367011    # pre-tanh rms 0.5 (136 at gain 1): stage rms 1.5 -> 5 -> 16 -> 108 -> 542, max 2.5e3 (seeded utterances)
+HOT_POST_BIAS = -0.0353616    # zero-mean waveform (std 0.40, |max| 0.96)
 
 
 def _xavier(rng, shape):
@@ -52,7 +60,7 @@ def _kaiming_default(rng, shape):
 
 
 def synth_state_dict(seed: int = 0, dur_mode: str = "parity", shapes: EVShapes | None = None,
-                     perturb: bool = True, voc_gain: float = 1.2, rb_gain: float = 2.2) -> Dict[str, np.ndarray]:
+                     perturb: bool = True, voc_gain: float = 1.2, rb_gain: float = 2.2, post_gain: float | None = None) -> Dict[str, np.ndarray]:
     """Return {reference state-dict key: float32 ndarray} (422 entries)."""
     s = shapes or EVShapes()
     rng = np.random.default_rng(seed)
@@ -117,6 +125,10 @@ def synth_state_dict(seed: int = 0, dur_mode: str = "parity", shapes: EVShapes |
     sd["am.embed_projection1.bias"] = bias(H)
 
     # duration head calibration
+    hot = dur_mode.endswith("_hot")
+    if hot:
+        dur_mode = dur_mode[:-4]
+        voc_gain, rb_gain = HOT_VOC_GAIN, HOT_RB_GAIN
     zero_dc = dur_mode.endswith("_zdc")
     if zero_dc:
         dur_mode = dur_mode[:-4]
@@ -165,10 +177,10 @@ def synth_state_dict(seed: int = 0, dur_mode: str = "parity", shapes: EVShapes |
                     p = f"generator.resblocks.{r}.{grp}.{d}"
                     b = wn_conv(p, (ch, ch, k), rb_gain)
                     conv_bias(p, ch, b)
-    b = wn_conv("generator.conv_post", (1, ch, 7), voc_gain)
+    b = wn_conv("generator.conv_post", (1, ch, 7), (HOT_POST_GAIN if hot else voc_gain) if post_gain is None else post_gain)
     conv_bias("generator.conv_post", 1, b)
     if zero_dc:
-        sd["generator.conv_post.bias"][...] = ZDC_POST_BIAS
+        sd["generator.conv_post.bias"][...] = HOT_POST_BIAS if hot else ZDC_POST_BIAS
     assert all(v is not None for v in sd.values())
     return sd
 

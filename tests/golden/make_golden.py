@@ -102,6 +102,10 @@ CASES = {
     "n24_alpha1p3": (0, "stress", 15, [24], [77], 1.3),
     # zero-mean waveform (conv_post bias = synthetic.ZDC_POST_BIAS): relative L2 without a DC term in the denominator
     "n28_zero_dc": (0, "parity_zdc", 16, [28], [123]),
+    # round 3: a full-length (BASELINE configs[1]-sized) zero-mean utterance, and trained-like generator gains: stage activations grow
+    # from O(1) to rms 540 / max 2.5e3 (synthetic.HOT_*) -- what fp16 storage has to survive with a released checkpoint
+    "n256_zero_dc": (0, "parity_zdc", 17, [256], [8]),
+    "n64_hot_zdc": (0, "parity_zdc_hot", 18, [64], [321]),
 }
 
 

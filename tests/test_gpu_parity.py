@@ -8,7 +8,8 @@ Two precisions of the frame-rate path are tested (include/evhip.h, EV_PREC_*):
   * "strict" (decoder + generator in split precision, fp32 activations): every output and every Appendix-C tap is held to
     TOL_STRICT = 2e-5 (measured <= 3.1e-6) -- fifty times inside the contract, also on the DC-free fixture;
   * "mx" (the contract mode: strict's data flow, cross terms of the >= 128-channel generator layers as block-scaled fp4 MFMAs):
-    mel as strict; waveform AND its DC-free measure <= TOL_MX = 1e-3 on every fixture, the zero-mean ones included (no exemption);
+    mel as strict; waveform AND its DC-free measure <= FAST_HOT = 4e-3         # fp16 operands on the trained-like ("_hot") zero-mean fixture: same mechanism, larger activations
+TOL_MX = 1e-3 on every fixture, the zero-mean ones included (no exemption);
   * "fast" (fp16 MFMA operands, the precision BASELINE.json's bf16 / fp16 configs name): mel and waveform <= 1e-3 on the
     synthetic-weight fixtures, whose waveform carries a DC offset ~3x its AC amplitude.  On a zero-mean waveform
     (tests/golden/n28_zero_dc.npz) fp16 operands measure ~2.2e-3: tools/precision_study.py attributes that evenly to the ~150
@@ -33,6 +34,7 @@ TOL_OUT = 1e-3          # north_star tolerance for mel and waveform
 TOL_F32_TAP = 1e-4      # fp32 token-rate taps
 TOL_STRICT = 2e-5       # every frame-rate quantity in the split-precision mode (measured <= 3.1e-6 over all tests)
 FAST_ZDC = 3e-3         # fp16 operands on a zero-mean waveform (measured 2.2e-3; see module docstring)
+FAST_HOT = 4e-3         # fp16 operands on the trained-like ("_hot") zero-mean fixture: same mechanism, larger activations
 TOL_MX = 1e-3           # "mx" mode: the north_star bound on EVERY fixture, zero-mean ones included, on the DC-free measure too
 NEAR_EPS = 2e-5         # |frac(exp(log_d) - 1) - 0.5| below which a duration may legitimately flip (log_d agrees to ~1e-6)
 REPORT = {}
@@ -120,6 +122,13 @@ def _check_durations(got, ref_dur, ref_logd):
     return int(diff.sum())
 
 
+def _tap_stride(g, prefix):
+    for k in g.files:
+        if k.startswith(prefix + "__ax1_s"):
+            return int(k.rsplit("_s", 1)[1])
+    return 0
+
+
 GOLDEN = sorted(p for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(p).startswith("simbert_"))
 
 
@@ -141,14 +150,18 @@ def test_golden_fixture(gpu, path, prec):
              wav_ac=rel_l2_ac(out["wav"], g["wav"]), wav_mean_over_std=float(abs(g["wav"].mean()) / g["wav"].std()))
     _report("golden/" + name, e)
     assert e["log_dur"] < TOL_F32_TAP and e["pitch"] < TOL_F32_TAP and e["energy"] < TOL_F32_TAP, e
-    zero_dc = str(g["dur_mode"]).endswith("_zdc")
+    zero_dc = "_zdc" in str(g["dur_mode"])
+    hot = str(g["dur_mode"]).endswith("_hot")       # trained-like generator gains: stage activations up to 2.5e3 (synthetic.HOT_*)
+    if hot:
+        assert np.abs(g["tap_voc_up3__ax1_s%d" % _tap_stride(g, "tap_voc_up3")]).max() > 300.0 if _tap_stride(g, "tap_voc_up3") else True
     if prec == "strict":
         assert e["mel"] < TOL_STRICT and e["wav"] < TOL_STRICT and e["wav_ac"] < TOL_STRICT, e
     elif prec == "mx":
         assert e["mel"] < TOL_STRICT and e["wav"] < TOL_MX and e["wav_ac"] < TOL_MX, e
     else:
         assert e["mel"] < (TOL_OUT if prec == "fast" else TOL_STRICT), e
-        assert e["wav"] < (FAST_ZDC if zero_dc else TOL_OUT), e
+        # fp16 storage neither saturates nor flushes at trained-like magnitudes: the error stays at the fp16-rounding level
+        assert e["wav"] < (FAST_HOT if hot else FAST_ZDC if zero_dc else TOL_OUT), e
     assert out["wav"].shape[0] == 256 * int(g["mel_len"])
     assert np.isfinite(out["wav"]).all() and np.abs(out["wav"]).max() <= 1.0
 
@@ -391,11 +404,16 @@ def test_config3_ragged_256_every_utterance(gpu, prec):
     assert rep["n"] == 256
 
 
-def test_config5_vocoder_only_fp16_properties(gpu):
-    """BASELINE configs[4] per-GPU share: 128 pre-computed 80 x 1024 fp16 mels through ev_vocoder.  Linearity does not hold
-    for a GAN vocoder; the size-independent properties are: exact lengths, bounded finite audio, every mel's waveform
-    bit-identical to the same mel vocoded alone (no cross-utterance leakage at any of the 4 upsampling stages)."""
-    eng = _engine("parity", "fast", keep=False)
+@pytest.mark.parametrize("prec", ["mx", "fast", "strict"])
+def test_config5_vocoder_only_full_size(gpu, prec):
+    """BASELINE configs[4] per-GPU share: 128 pre-computed 80 x 1024 fp16 mels through ev_vocoder.  (a) AGAINST THE ORACLE at full size:
+    two of the eight distinct mels (262 144 samples each) vs hifigan_forward on the same fp16-rounded mel, in every precision mode
+    (zero-mean weights: the DC-free measure is the contract figure); (b) the size-independent properties -- linearity does not hold
+    for a GAN vocoder --: exact lengths, bounded finite audio, every mel's waveform bit-identical to the same mel anywhere else in the
+    batch and vocoded alone (no cross-utterance leakage at any of the 4 upsampling stages)."""
+    from oracle import EVShapes, hifigan_forward
+    eng = _engine("parity_zdc", prec, keep=False)
+    sd, _, _ = _weights("parity_zdc")
     rng = np.random.default_rng(9)
     base = (1.25 * rng.standard_normal((8, 80, 1024)) + 0.08).astype(np.float16)
     mels = [base[i % 8] for i in range(128)]
@@ -404,6 +422,13 @@ def test_config5_vocoder_only_fp16_properties(gpu):
     first = [out["wav_list"][i].copy() for i in range(8)]
     for i in range(8, 128):
         assert np.array_equal(out["wav_list"][i], first[i % 8]), i          # identical mels -> identical audio anywhere in the batch
+    errs = {}
+    for i in (0, 5):
+        ref = hifigan_forward(sd, torch.from_numpy(base[i].astype(np.float32)), EVShapes()).numpy()
+        errs[i] = (rel_l2(first[i], ref), rel_l2_ac(first[i], ref))
+    _report("config5_full_size/" + prec, {str(k): v for k, v in errs.items()})
+    bound = {"strict": TOL_STRICT, "mx": TOL_MX, "fast": FAST_ZDC}[prec]
+    assert max(max(v) for v in errs.values()) < bound, errs
     solo = eng.vocoder([mels[3]])
     assert np.array_equal(solo["wav"], first[3])
 
