@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ev_gemm.hip", "ev_misc.hip", "ev_engine.cpp"]
-HEADERS = ["ev_kernels.h", "ev_gemm_mx.h", "../../include/evhip.h", "../../include/evhip_ops.h"]
+HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + ["../../include/evhip.h", "../../include/evhip_ops.h"]      # every header in csrc/: a stale .so cost round 3 an hour of wrong measurements
 OUT = os.path.join(HERE, "libevhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

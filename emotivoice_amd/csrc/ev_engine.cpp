@@ -336,7 +336,7 @@ ConvGemmParams gemm_defaults() {
 // token-rate (fp32) GEMM operands: exact fp32 MFMA or the hi/lo split pair (cfg.token_rate_split)
 int tok_weights(ev_handle* h, const std::string& base /* e.g. "enc.0.qkv.w" */, ConvGemmParams& p) {
     const bool dec = base.compare(0, 4, "dec.") == 0 || base.compare(0, 7, "to_mel.") == 0;
-    if (dec ? h->cfg.decoder_precision == EV_PREC_X3 : h->cfg.token_rate_split != 0) {
+    if (dec ? (h->cfg.decoder_precision == EV_PREC_X3 || h->cfg.decoder_precision == EV_PREC_MX) : h->cfg.token_rate_split != 0) {
         // hi part: fp16(w).  The token-rate stack packs it as "<name>32h"; for the decoder it is the fp16 copy "<name>16"
         const WeightEntry* hi = W(h, base + (h->wt.count(base + "32h") ? "32h" : "16"));
         const WeightEntry* lo = W(h, base + "32l");
@@ -350,6 +350,30 @@ int tok_weights(ev_handle* h, const std::string& base /* e.g. "enc.0.qkv.w" */, 
     return 0;
 }
 
+// raw storage of one MX plane set (ev_gemm_mx.h), sized for the largest [rows][C] it will hold; mx_view() lays a tensor into it
+struct PlaneBuf { char* h = nullptr; char* q4[2] = {nullptr, nullptr}; char* qs[2] = {nullptr, nullptr}; };
+struct MxView { char* h; char* q4[2]; char* qs[2]; unsigned qs_stride; int logC; };
+static constexpr size_t MX_PAD = 64;        // slack rows of every plane, both sides
+MxView mx_view(const PlaneBuf& b, size_t rows, int C) {
+    MxView v;
+    v.h = b.h + MX_PAD * C * 2;
+    for (int i = 0; i < 2; ++i) { v.q4[i] = b.q4[i] + MX_PAD * (C / 2); v.qs[i] = b.qs[i] + MX_PAD * 4; }
+    v.qs_stride = (unsigned)((rows + 2 * MX_PAD) * 4);
+    v.logC = ilog2(C);
+    return v;
+}
+void mx_out(ConvGemmParams& p, const MxView& v, float slope) {
+    p.mxo_h = v.h; p.mxo_q4[0] = v.q4[0]; p.mxo_q4[1] = v.q4[1]; p.mxo_qs[0] = v.qs[0]; p.mxo_qs[1] = v.qs[1];
+    p.mxo_qs_stride = v.qs_stride; p.mxo_logC = v.logC; p.mxo_slope = slope;
+}
+void mx_in(ConvGemmParams& p, const MxView& v, int C) {
+    p.A = v.h; p.lda = C; p.pro_lrelu = 0;
+    p.mx_x4[0] = v.q4[0]; p.mx_x4[1] = v.q4[1]; p.mx_xs[0] = v.qs[0]; p.mx_xs[1] = v.qs[1]; p.mx_xs_stride = v.qs_stride;
+}
+
+// EV_PREC_MX decoder: plane set of the conv-FFN's hidden activation [R][4C] and the planes-kernel scratch of its fp32 input [R][C]
+struct DecMx { PlaneBuf ffn; char* scratch; size_t scratch_bytes; };
+
 struct RowCtx {     // one row layout (token rate or frame rate)
     int R; const uint8_t* valid; const int32_t* row_seq; const int32_t* seq_off; const int32_t* seq_len; int B; int max_len;
     double n_valid;
@@ -358,7 +382,7 @@ struct RowCtx {     // one row layout (token rate or frame rate)
 // Encoder / decoder stack (reference modules/encoder.py:316-324, layer :154-200).  x (fp32 residual stream,
 // [R][C]) is updated in place; y receives after_norm(x) in `prec` dtype (and y32_tap in fp32 if given).
 int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx& rc, Buf& x, Buf& hbuf, Buf& qkv, Buf& ctx, Buf& ffn,
-              Buf& y, float* y32_tap, std::vector<Buf>* layer_taps) {
+              Buf& y, float* y32_tap, std::vector<Buf>* layer_taps, const DecMx* dmx = nullptr) {
     const int C = h->cfg.hidden, F = 4 * C, kf = h->cfg.ffn_kernel;
     const char* wsuf = prec == DT_F16 ? "w16" : "w32";
     const std::string sp(pre);
@@ -397,13 +421,22 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         p.dtype = prec; p.A = hbuf.p; p.lda = C; p.W = wf1; p.bias = bf1; p.M = rc.R; p.N = F; p.K = C; p.taps = kf; p.center = (kf - 1) / 2;
         p.row_valid = rc.valid; p.act = ACT_GELU; p.ldo = F;
         if (prec == DT_F32 && tok_weights(h, lp + ".ffn1.w", p)) return -1;
-        if (prec == DT_F16) p.out16 = ffn.p; else p.out32 = (float*)ffn.p;
-        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        // EV_PREC_MX decoder: the conv-FFN (72 % of the stack's FLOPs) on the MX kernel; its hidden activation only exists as conv2's operand planes
+        const bool ffn_mx = dmx && p.dtype == DT_F32S && h->wt.count(lp + ".ffn1.wmx") && h->wt.count(lp + ".ffn2.wmx");
+        MxView fv{};
+        if (ffn_mx) {
+            fv = mx_view(dmx->ffn, (size_t)rc.R, F);
+            fv.logC = 0;                                          // dense [R][F] geometry (F = 1536 is not a power of two)
+            p.dtype = DT_MX; p.W_mx = h->wt[lp + ".ffn1.wmx"].ptr; p.mx_scratch = dmx->scratch; p.mx_scratch_size = dmx->scratch_bytes;
+            mx_out(p, fv, 1.0f);
+        } else if (prec == DT_F16) p.out16 = ffn.p; else p.out32 = (float*)ffn.p;
+        if (gemm(h, ffn_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         p = gemm_defaults();
         p.dtype = prec; p.A = ffn.p; p.lda = F; p.W = wf2; p.bias = bf2; p.M = rc.R; p.N = C; p.K = F; p.taps = kf; p.center = (kf - 1) / 2;
         p.row_valid = rc.valid; p.res = x.p; p.res_dtype = DT_F32; p.ldres = C; p.out32 = (float*)x.p; p.ldo = C;
         if (prec == DT_F32 && tok_weights(h, lp + ".ffn2.w", p)) return -1;
-        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        if (ffn_mx) { p.dtype = DT_MX; p.W_mx = h->wt[lp + ".ffn2.wmx"].ptr; mx_in(p, fv, F); }
+        if (gemm(h, ffn_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         if (layer_taps) HIPCHK(h, hipMemcpyAsync((*layer_taps)[i].p, x.p, x.bytes, hipMemcpyDeviceToDevice, h->stream));
     }
     WPTR(ga, float, sp + ".after.g"); WPTR(ba, float, sp + ".after.b");
@@ -452,27 +485,6 @@ int run_predictor(ev_handle* h, const char* name, int layers, const RowCtx& rc, 
     return 0;
 }
 
-// raw storage of one MX plane set (ev_gemm_mx.h), sized for the largest [rows][C] it will hold; mx_view() lays a tensor into it
-struct PlaneBuf { char* h = nullptr; char* q4[2] = {nullptr, nullptr}; char* qs[2] = {nullptr, nullptr}; };
-struct MxView { char* h; char* q4[2]; char* qs[2]; unsigned qs_stride; int logC; };
-static constexpr size_t MX_PAD = 64;        // slack rows of every plane, both sides
-MxView mx_view(const PlaneBuf& b, size_t rows, int C) {
-    MxView v;
-    v.h = b.h + MX_PAD * C * 2;
-    for (int i = 0; i < 2; ++i) { v.q4[i] = b.q4[i] + MX_PAD * (C / 2); v.qs[i] = b.qs[i] + MX_PAD * 4; }
-    v.qs_stride = (unsigned)((rows + 2 * MX_PAD) * 4);
-    v.logC = ilog2(C);
-    return v;
-}
-void mx_out(ConvGemmParams& p, const MxView& v, float slope) {
-    p.mxo_h = v.h; p.mxo_q4[0] = v.q4[0]; p.mxo_q4[1] = v.q4[1]; p.mxo_qs[0] = v.qs[0]; p.mxo_qs[1] = v.qs[1];
-    p.mxo_qs_stride = v.qs_stride; p.mxo_logC = v.logC; p.mxo_slope = slope;
-}
-void mx_in(ConvGemmParams& p, const MxView& v, int C) {
-    p.A = v.h; p.lda = C; p.pro_lrelu = 0;
-    p.mx_x4[0] = v.q4[0]; p.mx_x4[1] = v.q4[1]; p.mx_xs[0] = v.qs[0]; p.mx_xs[1] = v.qs[1]; p.mx_xs_stride = v.qs_stride;
-}
-
 struct VocBufs {
     Buf pre, xu[4], tmp[3], rba[3], rbb[3], nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap;
     // EV_PREC_MX: plane sets of the up-conv output, conv1's output, the two alternating ResBlock states and the stage output; the
@@ -492,6 +504,7 @@ int voc_weights(ev_handle* h, const std::string& base /* e.g. "voc.rb3.c1.0" */,
         p.dtype = DT_F32S; p.W_lo = lo->ptr;
         if (mx) {           // layers with fp4 planes in the blob (N, K % 128 == 0, 3 / 7 / 11 taps: packer.py) take the MX kernel
             auto it = h->wt.find(base + ".wmx");
+            if (it == h->wt.end()) it = h->wt.find(base + ".wcmx");          // C = 64 layers: conv_c64_mx_kernel's planes (fp32 in / out)
             if (it != h->wt.end()) { p.dtype = DT_MX; p.W_mx = it->second.ptr; }
         }
     } else {
@@ -513,7 +526,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
     const size_t ves = x3 ? 4 : 2;
     auto set_out = [&](ConvGemmParams& q, void* dst) { if (x3) q.out32 = (float*)dst; else q.out16 = dst; };
     auto has_wt = [&](const std::string& name) { return h->wt.find(name) != h->wt.end(); };
-    auto has_mx = [&](const std::string& base) { return mx && has_wt(base + ".wmx"); };
+    auto has_mx = [&](const std::string& base) { return mx && (has_wt(base + ".wmx") || has_wt(base + ".wcmx")); };
     bool prev_planes = false;           // vb.pl_nxt holds the plane set of lrelu(prev)
     ConvGemmParams p = gemm_defaults();
     if (voc_weights(h, "voc.pre", x3, p)) return -1;
@@ -540,7 +553,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         if (x3) { p.pro_lrelu = 1; p.pro_slope = 0.1f; }          // models.py:118 (the fp16 path has it in the producer's epilogue)
         set_out(p, vb.xu[i].p);
         // the ResBlocks of this stage run on the MX kernel iff all their convs have fp4 planes (shape rule of the packer)
-        bool stage_mx = mx && cout % 128 == 0;
+        bool stage_mx = mx && cout % 64 == 0;            // (C = 64: conv_c64_mx_kernel, the same plane-set data flow)
         for (int j = 0; stage_mx && j < c.n_rb; ++j) stage_mx = has_mx("voc.rb" + std::to_string(i * c.n_rb + j) + ".c1.0");
         if (p.dtype == DT_MX) {
             if (prev_planes) mx_in(p, mx_view(vb.pl_nxt, rows_in, ch), ch);            // the previous stage's epilogue wrote lrelu(prev) as planes
@@ -549,7 +562,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         }
         if (p.dtype == DT_MX && stage_mx) mx_out(p, mx_view(vb.pl_xu, (size_t)rows_out, cout), 0.1f);      // lrelu(x) of models.py:51, shared by the three ResBlocks
         else stage_mx = false;
-        if (gemm(h, p.dtype == DT_MX ? "voc_conv_gemm_mx" : gname, p, valid_in, nullptr, 2.0 / 3.0)) return -1;
+        if (gemm(h, p.dtype == DT_MX ? (p.N == 64 && p.K == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx") : gname, p, valid_in, nullptr, 2.0 / 3.0)) return -1;
         const bool next_up_mx = stage_mx && i + 1 < c.n_up && has_mx("voc.up" + std::to_string(i + 1));
         U *= s;
         const int shift = ilog2(U);
@@ -622,21 +635,21 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     p.M = rows_out; p.N = cout; p.K = cout; p.taps = k; p.dil = dil; p.center = (k - 1) / 2;
                     p.row_valid = h->d_frm_valid; p.valid_shift = shift; p.act = ACT_LRELU; p.act_slope = 0.1f; p.ldo = cout;
                     mx_out(p, mx_view(vb.pl_t, (size_t)rows_out, cout), 1.0f);
-                    if (gemm(h, "voc_conv_gemm_mx", p, valid_out, sj)) return -1;
+                    if (gemm(h, cout == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx", p, valid_out, sj)) return -1;
                 } else if (!fused) {
                     // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
                     p = gemm_defaults();
-                    if (voc_weights(h, c1, x3, p)) return -1;
+                    if (voc_weights(h, c1, x3, p, mx && cout == 64)) return -1;
                     p.A = xcur; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
                     p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
                     p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.ldo = cout;
                     set_out(p, vb.tmp[bj].p);
                     const int e1 = (2 * (c.n_rb_dils - 1 - d) + 1) * 256, lo1 = std::max(0, a0 - e1), hi1 = std::min(rows_out, b0 + e1);
-                    if (gemm(h, gname, sub(p, lo1, hi1), valid_out * frac, sj)) return -1;
+                    if (gemm(h, p.dtype == DT_MX ? "voc_conv_c64_mx" : gname, sub(p, lo1, hi1), valid_out * frac, sj)) return -1;
                 }
                 // x = c2(xt) + x  (models.py:54-56)
                 p = gemm_defaults();
-                if (voc_weights(h, c2, x3, p, stage_mx)) return -1;
+                if (voc_weights(h, c2, x3, p, stage_mx || (mx && cout == 64))) return -1;
                 p.A = vb.tmp[bj].p; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
                 if (stage_mx) {
                     if (p.dtype != DT_MX) return fail(h, "MX stage: %s has no fp4 planes", c2.c_str());
@@ -699,7 +712,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0, sj, &shape);
                     if (cout == 32) launch_resblock_pair_c32(rp, sj);
                     else launch_resblock_pair_c64(rp, sj);
-                } else if (gemm(h, p.dtype == DT_MX ? "voc_conv_gemm_mx" : gname, p, valid_out * frac, sj)) return -1;
+                } else if (gemm(h, p.dtype == DT_MX ? (cout == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx") : gname, p, valid_out * frac, sj)) return -1;
             }
             if (conc && j < 2) (void)hipEventRecord(h->ev_join[j], h->aux[j]);
         }
@@ -759,9 +772,9 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
         ch = c.up_init_ch; U = 1;
         for (int i = 0; i < c.n_up; ++i) {
             U *= c.up_rates[i]; ch /= 2;
-            if (ch % 128) continue;
+            if (ch % 64) continue;
             const size_t R = (size_t)Rf * U + 2 * MX_PAD;
-            hb = std::max(hb, R * ch * 2); qb = std::max(qb, R * (ch / 2)); sb = std::max(sb, (size_t)(ch / 128) * R * 4);
+            hb = std::max(hb, R * ch * 2); qb = std::max(qb, R * (ch / 2)); sb = std::max(sb, (size_t)std::max(1, ch / 128) * R * 4);
         }
         PlaneBuf* sets[5] = {&vb.pl_xu, &vb.pl_t, &vb.pl_a, &vb.pl_b, &vb.pl_nxt};
         for (PlaneBuf* b : sets) {
@@ -883,7 +896,8 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
                 }
         }
     }
-    if (cfg->decoder_precision != EV_PREC_F16 && cfg->decoder_precision != EV_PREC_F32 && cfg->decoder_precision != EV_PREC_X3)
+    if (cfg->decoder_precision != EV_PREC_F16 && cfg->decoder_precision != EV_PREC_F32 && cfg->decoder_precision != EV_PREC_X3 &&
+        cfg->decoder_precision != EV_PREC_MX)
         return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
     if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3 && cfg->vocoder_precision != EV_PREC_MX)
         return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16, EV_PREC_X3 or EV_PREC_MX");
@@ -1239,6 +1253,8 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
     VocBufs vb;
     int Rf = 0;
     const size_t esd = dec_prec == DT_F16 ? 2 : 4;
+    const bool dec_mx = c.decoder_precision == EV_PREC_MX && C % 128 == 0;
+    DecMx dmx{};
     { int64_t r = GAP; for (int b = 0; b < B; ++b) r += h->mel_lens[b] + GAP; Rf = (int)align_up((size_t)r, ROW_ALIGN); }
     if ((size_t)B > PIN_MAX_B) return fail(h, "at most %zu utterances per call", PIN_MAX_B);
     if (pinned_reserve(h, PIN_BYTES)) return -1;
@@ -1249,6 +1265,13 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         build_frame_layout(h, ap, pass == 0, B);
         fb.x = ap.rows(Rf, C, 4); fb.hb = ap.rows(Rf, C, esd); fb.qkv = ap.rows(Rf, 3 * C, esd); fb.ctx = ap.rows(Rf, C, esd);
         fb.ffn = ap.rows(Rf, 4 * C, esd); fb.y = ap.rows(Rf, C, esd); fb.mel32 = ap.rows(Rf, MEL_PAD, 4); fb.mel16 = ap.rows(Rf, MEL_PAD, 2);
+        if (dec_mx) {
+            const size_t R = (size_t)Rf + 2 * MX_PAD, F = 4 * (size_t)C;
+            dmx.ffn.h = ap.take(R * F * 2);
+            for (int i = 0; i < 2; ++i) { dmx.ffn.q4[i] = ap.take(R * F / 2); dmx.ffn.qs[i] = ap.take(F / 128 * R * 4); }
+            dmx.scratch_bytes = mx_scratch_bytes(Rf, C);
+            dmx.scratch = ap.take(dmx.scratch_bytes);
+        }
         if (keep) { fb.ltaps.resize(c.dec_layers); for (auto& b : fb.ltaps) b = ap.rows(Rf, C, 4); fb.up_tap = ap.rows(Rf, C, 4); fb.y_tap = ap.rows(Rf, C, 4); }
         fb.d_mel = ap.arr<float>((size_t)h->total_frames * c.n_mels);
         if (!(flags & EV_FLAG_NO_VOCODER)) {
@@ -1265,7 +1288,7 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
       launch_gauss_upsample((const float*)tb.xvar.p, (const float*)tb.centre.p, h->d_tok_off, h->d_tok_len, h->d_frm_seq, h->d_frm_pos, pe,
                             alphas[1], 0.1f, (float*)fb.x.p, keep ? (float*)fb.up_tap.p : nullptr, Rf, C, h->stream); }
     if (run_stack(h, "dec", c.dec_layers, dec_prec, frc, fb.x, fb.hb, fb.qkv, fb.ctx, fb.ffn, fb.y,
-                  (keep && dec_prec == DT_F16) ? (float*)fb.y_tap.p : nullptr, keep ? &fb.ltaps : nullptr)) return -1;
+                  (keep && dec_prec == DT_F16) ? (float*)fb.y_tap.p : nullptr, keep ? &fb.ltaps : nullptr, dec_mx ? &dmx : nullptr)) return -1;
     {
         WPTR(wm, char, dec_prec == DT_F16 ? "to_mel.w16" : "to_mel.w32"); WPTR(bm, float, "to_mel.b");
         ConvGemmParams p = gemm_defaults();

@@ -268,6 +268,9 @@ __device__ __forceinline__ unsigned mx_scale_byte(float amax) {
     const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 2;
     return (unsigned)min(max(e, 1), 254);
 }
+// value of lane ^ 1 / lane ^ 2 (v_mov_b32_dpp quad_perm:[1,0,3,2] / [2,3,0,1])
+__device__ __forceinline__ float quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
 // 8 consecutive channels a[0..3] (packed pairs) of one lane -> their share of the plane set: ho = the fp16 hi parts, ch / cl = the eight fp4
 // codes of the hi parts / of the fp32 remainders, bh / bl = the E8M0 scale bytes of the 32-channel block the lane belongs to.  The four
 // lanes of a block are consecutive (lane & 3 = position in the block) and agree on the block maxima by two quad shuffles.
@@ -283,8 +286,10 @@ __device__ __forceinline__ void mx_quant8(const f32x2 (&a)[4], uint4& ho, unsign
         mh = max_raw(mh, max_raw(__builtin_fabsf(hf[j][0]), __builtin_fabsf(hf[j][1])));
         ml = max_raw(ml, max_raw(__builtin_fabsf(lf[j][0]), __builtin_fabsf(lf[j][1])));
     }
-    mh = max_raw(mh, __shfl_xor(mh, 1)); mh = max_raw(mh, __shfl_xor(mh, 2));
-    ml = max_raw(ml, __shfl_xor(ml, 1)); ml = max_raw(ml, __shfl_xor(ml, 2));
+    // (DPP quad permutes: __shfl_xor compiles to ds_bpermute_b32 -- an LDS-pipe round trip with its own address arithmetic, four of them in
+    // a dependent chain per call, which measured a third of conv_c64_mx_kernel's k = 3 launches)
+    mh = max_raw(mh, quad_xor1(mh)); mh = max_raw(mh, quad_xor2(mh));
+    ml = max_raw(ml, quad_xor1(ml)); ml = max_raw(ml, quad_xor2(ml));
     bh = mx_scale_byte(mh); bl = mx_scale_byte(ml);
     const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);       // the block scales as fp32 (2^(b - 127))
     ch = 0; cl = 0;                                                                    // v_cvt_scalef32_pk_fp4_f32: fp4(x / scale), RNE, saturating
@@ -297,7 +302,9 @@ __device__ __forceinline__ void mx_quant8(const f32x2 (&a)[4], uint4& ho, unsign
 }
 // One lane = 8 consecutive channels at linear element offset `lin` of the [rows][C] tensor: writes 16 B of the fp16 hi plane, 4 B of each
 // code plane and (first lane of the block) one byte of each scale plane.
-__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, int lane) {
+// (row, co) = the element's position in the launch's own [M][N] output; mxo_logC == 0: that IS the plane set's geometry (C = N, any multiple
+// of 128), else the planes are [M * N / C][C] with C = 2^mxo_logC (a transposed conv's polyphase output).
+__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, long row_, int co, int lane) {
     uint4 ho;
     unsigned ch, cl, bh, bl;
     mx_quant8(a, ho, ch, cl, bh, bl);
@@ -305,8 +312,8 @@ __device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f3
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;
     if ((lane & 3) == 0) {
-        const long row = lin >> p.mxo_logC;
-        const unsigned c = (unsigned)lin & ((1u << p.mxo_logC) - 1u);
+        const long row = p.mxo_logC ? (lin >> p.mxo_logC) : row_;
+        const unsigned c = p.mxo_logC ? ((unsigned)lin & ((1u << p.mxo_logC) - 1u)) : (unsigned)co;
         const long so = (long)(c >> 7) * p.mxo_qs_stride + row * 4 + ((c >> 5) & 3);
         reinterpret_cast<uint8_t*>(p.mxo_qs[0])[so] = (uint8_t)bh;
         reinterpret_cast<uint8_t*>(p.mxo_qs[1])[so] = (uint8_t)bl;
@@ -479,7 +486,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 f32x2 am[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { am[j] = lrelu2(v[j], mxo_slope2); am[j][0] = valid ? am[j][0] : 0.f; am[j][1] = valid ? am[j][1] : 0.f; }
-                mx_emit_planes(p, am, off, lane);
+                mx_emit_planes(p, am, off, (long)trow + pass * 32 + it * RPI, co, lane);
             }
             EV_STAMP()
         }
@@ -2240,6 +2247,8 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
 #include "ev_gemm_mx.h"
 #include "ev_pair_mx.h"
 
+#include "ev_conv64_mx.h"
+
 int init_device_kernels(int device) {
     if (device < 0 || device >= 64) return -1;
     hipDeviceProp_t prop;
@@ -2260,6 +2269,7 @@ int init_device_kernels(int device) {
     if (phased_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (pair_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
+    if (conv64_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     g_dev_ready[device] = (e == hipSuccess);
     return e == hipSuccess ? 0 : -1;
 }
@@ -2300,7 +2310,8 @@ void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {
     if (p.dtype == DT_F16) launch_dt<_Float16>(p, s);
     else if (p.dtype == DT_F32S) launch_split(p, s);
     else if (p.dtype == DT_MX) {
-        if (mx_eligible(p)) launch_mx(p, s);
+        if (conv64_mx_eligible(p)) launch_conv64_mx(p, s);
+        else if (mx_eligible(p)) launch_mx(p, s);
         else { ConvGemmParams q = p; q.dtype = DT_F32S; launch_split(q, s); }      // same operands, three fp16 MFMAs per product
     } else launch_dt<float>(p, s);
 }

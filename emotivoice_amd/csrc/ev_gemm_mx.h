@@ -313,8 +313,10 @@ static int mx_epi_variant(const ConvGemmParams& p) {
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
     const bool odd_slope = p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f);
     const bool mxp = p.mxo_h != nullptr;
-    if (mxp && !(p.mxo_q4[0] && p.mxo_q4[1] && p.mxo_qs[0] && p.mxo_qs[1] && p.ldo == p.N && p.mxo_logC >= 7 && p.mxo_logC <= 12 &&
-                 p.N % (1 << p.mxo_logC) == 0 && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f)) return -1;
+    if (mxp && !(p.mxo_q4[0] && p.mxo_q4[1] && p.mxo_qs[0] && p.mxo_qs[1] && p.ldo == p.N && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f &&
+                 (p.mxo_logC == 0 || (p.mxo_logC >= 6 && p.mxo_logC <= 12 && p.N % (1 << p.mxo_logC) == 0)))) return -1;
+    if (mxp && rare_act && !p.out32 && !p.res && !p.acc32 && !p.seq_bias && !p.add16_a && !p.out16 && !p.post_lrelu)
+        return EPI_RARE_ACT | EPI_MXP;                                       // conv-FFN's first conv: erf-GELU, planes only
     if (p.seq_bias || p.add16_a || p.out16 || p.out32_before_post || p.post_lrelu || odd_slope || rare_act) return mxp ? -1 : EPI_GENERIC;
     const bool res32 = p.res && p.res_dtype == DT_F32;
     if (p.res && !res32) return mxp ? -1 : EPI_GENERIC;
@@ -326,7 +328,7 @@ static int mx_epi_variant(const ConvGemmParams& p) {
     return mxp ? -1 : EPI_GENERIC;
 }
 #define EV_MX_VARIANTS(X) X(EPI_O32) X(EPI_RES32 | EPI_O32 | EPI_LEAN) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_MXP) X(EPI_O32 | EPI_MXP) \
-    X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_GENERIC)
+    X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RARE_ACT | EPI_MXP) X(EPI_GENERIC)
 template <int TAPS>
 static void launch_mx_taps(const ConvGemmParams& p, int e, hipStream_t s) {
     switch (e) {
@@ -365,9 +367,10 @@ static bool mx_eligible(const ConvGemmParams& p) {
     return p.mx_scratch && p.mx_scratch_size >= mx_scratch_bytes(p.M, p.K);
 }
 // 0 = this DT_MX call can run (as the MX kernel, or -- fp32 input, no plane output -- as the split-precision fallback)
+static bool conv64_mx_eligible(const ConvGemmParams& p);
 int mx_check(const ConvGemmParams& p) {
     if (p.dtype != DT_MX) return p.mxo_h || mx_planes_in(p) ? -1 : 0;       // plane sets exist only between DT_MX launches
-    if (mx_eligible(p)) return 0;
+    if (mx_eligible(p) || conv64_mx_eligible(p)) return 0;
     return (p.mxo_h || mx_planes_in(p) || !p.W_lo) ? -1 : 0;
 }
 static void launch_mx(const ConvGemmParams& p_in, hipStream_t s) {

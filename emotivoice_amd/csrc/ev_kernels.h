@@ -45,8 +45,8 @@ struct ConvGemmParams {
     const void* W_mx; void* mx_scratch; size_t mx_scratch_size;
     const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int reserved2;
     // Plane-set OUTPUT (any dtype whose launch takes an EPI_MXP epilogue: DT_MX kernels): besides / instead of out32 the epilogue writes
-    // the planes of a = lrelu(result, mxo_slope) (slope 1 = none) viewed as [rows][2^mxo_logC] (ldo == N; a transposed conv's
-    // [M][s * C] output is the [M * s][C] tensor): mxo_h fp16(a); mxo_q4[0] / [1] fp4 codes of fp16(a) and of a - fp16(a), C / 2 bytes
+    // the planes of a = lrelu(result, mxo_slope) (slope 1 = none) viewed as [rows][C], C = 2^mxo_logC, or C = N when mxo_logC == 0
+    // (ldo == N; a transposed conv's [M][s * C] output is the [M * s][C] tensor): mxo_h fp16(a); mxo_q4[0] / [1] fp4 codes of fp16(a) and of a - fp16(a), C / 2 bytes
     // per row; mxo_qs[0] / [1] their E8M0 block scales, one byte per 32 channels, chunk-major [C / 128][mxo_qs_stride / 4 rows][4].
     // Invalid rows give all-zero planes.  Every plane needs 64 readable slack rows on both sides for its consumer.
     void* mxo_h; void* mxo_q4[2]; void* mxo_qs[2]; unsigned mxo_qs_stride; int mxo_logC; float mxo_slope; int reserved3;

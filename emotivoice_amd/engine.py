@@ -27,7 +27,7 @@ def resolve_precision(precision, decoder_precision, vocoder_precision):
     if precision not in (None, "fast", "strict", "mx"):
         raise ValueError("precision must be 'fast', 'strict' or 'mx'")
     if precision == "mx":
-        return decoder_precision or "x3", vocoder_precision or "mx"
+        return decoder_precision or "mx", vocoder_precision or "mx"
     base = "x3" if precision == "strict" else "f16"
     return decoder_precision or base, vocoder_precision or base
 

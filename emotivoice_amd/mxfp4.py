@@ -137,3 +137,37 @@ def pair_weight_planes_dequant(blob: np.ndarray, taps: int):
         sb = blob[2 * nc + i * ns:2 * nc + (i + 1) * ns].reshape(kp, 32)[:taps].T[..., None]
         res.append(dequantize(np.ascontiguousarray(c), np.ascontiguousarray(sb), 32))
     return res[0], res[1]
+
+
+def pack_c64_weight_planes(w: np.ndarray) -> np.ndarray:
+    """GEMM-layout weight [64][taps][64] fp32 of a C = 64 conv -> the fp4 planes of conv_c64_mx_kernel (ev_conv64_mx.h):
+         codes  [plane: Q(w - fp16(w)), Q(fp16(w))][output-channel half][KP taps][32 co][32 B]
+         scales [plane][half][KP][32 co][2]          (one per (output channel, tap, 32 input channels) = per MFMA k-block)
+    taps padded to KP = a multiple of two with zero codes (one v_mfma_scale_f32_16x16x128 covers two taps x 64 channels)."""
+    w = np.ascontiguousarray(w, np.float32)
+    N, taps, K = w.shape
+    assert N == 64 and K == 64, (N, K)
+    kp = (taps + 1) // 2 * 2
+    hi, lo = split_hi_lo(w)
+    codes, scales = [], []
+    for part in (lo, hi):
+        c, sb = quantize(part, 32)                           # [64][taps][32 B], [64][taps][2]
+        cp = np.zeros((2, kp, 32, 32), np.uint8)
+        sp = np.ones((2, kp, 32, 2), np.uint8)
+        cp[:, :taps] = c.reshape(2, 32, taps, 32).transpose(0, 2, 1, 3)
+        sp[:, :taps] = sb.reshape(2, 32, taps, 2).transpose(0, 2, 1, 3)
+        codes.append(cp.reshape(-1))
+        scales.append(sp.reshape(-1))
+    return np.concatenate(codes + scales)
+
+
+def c64_weight_planes_dequant(blob: np.ndarray, taps: int):
+    """inverse of pack_c64_weight_planes (tests): -> (Q(wl), Q(wh)) as fp32 [64][taps][64]."""
+    kp = (taps + 1) // 2 * 2
+    nc, ns = 2 * kp * 32 * 32, 2 * kp * 32 * 2
+    res = []
+    for i in range(2):
+        c = blob[i * nc:(i + 1) * nc].reshape(2, kp, 32, 32)[:, :taps].transpose(0, 2, 1, 3).reshape(64, taps, 32)
+        sb = blob[2 * nc + i * ns:2 * nc + (i + 1) * ns].reshape(2, kp, 32, 2)[:, :taps].transpose(0, 2, 1, 3).reshape(64, taps, 2)
+        res.append(dequantize(np.ascontiguousarray(c), np.ascontiguousarray(sb), 32))
+    return res[0], res[1]

@@ -156,6 +156,13 @@ class _Blob:
             from .mxfp4 import pack_pair_weight_planes
             self.raw(name, pack_pair_weight_planes(w))
 
+    def mx_c64(self, name: str, w: np.ndarray):
+        """fp4 planes of a C = 64 conv (ResBlock convs of stage 2, the last up-conv) for conv_c64_mx_kernel (mxfp4.pack_c64_weight_planes)."""
+        N, taps, K = w.shape
+        if N == 64 and K == 64 and taps in (3, 7, 11):
+            from .mxfp4 import pack_c64_weight_planes
+            self.raw(name, pack_c64_weight_planes(w))
+
     def finish(self) -> Tuple[bytes, dict]:
         n = len(self.items)
         off = 16 + n * _ENTRY.size
@@ -215,6 +222,8 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
                 b.lo(f"{short}.{i}.qkv.w32l", np.concatenate(wq, 0)[:, None, :])
                 b.lo(f"{short}.{i}.out.w32l", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
                 b.lo(f"{short}.{i}.ffn1.w32l", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))
+                b.mx(f"{short}.{i}.ffn1.wmx", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))       # "mx" decoder: conv-FFN on the MX kernel
+                b.mx(f"{short}.{i}.ffn2.wmx", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
                 b.lo(f"{short}.{i}.ffn2.w32l", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
             b.add(f"{short}.{i}.qkv.b", np.concatenate(bq, 0), DT_F32)
             b.both(f"{short}.{i}.out.w", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
@@ -269,6 +278,7 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
         b.add(f"voc.up{i}.w16", wup, DT_F16)
         b.lo(f"voc.up{i}.w16l", wup)
         b.mx(f"voc.up{i}.wmx", wup)
+        b.mx_c64(f"voc.up{i}.wcmx", wup)
         b.add(f"voc.up{i}.b", np.tile(f32(f"{g}.ups.{i}.bias"), u), DT_F32)
         ch //= 2
         for j in range(nk):
@@ -281,6 +291,7 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
                     b.lo(f"voc.rb{r}.{short}.{d}.w16l", wrb)
                     b.mx(f"voc.rb{r}.{short}.{d}.wmx", wrb)
                     b.mx_pair(f"voc.rb{r}.{short}.{d}.wpmx", wrb)
+                    b.mx_c64(f"voc.rb{r}.{short}.{d}.wcmx", wrb)
                     b.add(f"voc.rb{r}.{short}.{d}.b", f32(pre + ".bias"), DT_F32)
     wpost = _fold_weight_norm(sd, f"{g}.conv_post")     # [1, C, 7]
     b.add("voc.post.w", np.ascontiguousarray(wpost[0].T), DT_F32)   # [7][C]

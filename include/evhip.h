@@ -62,7 +62,8 @@ typedef struct ev_config {
     int32_t n_rb_dils;          /* 3     */
     int32_t sample_rate;        /* 16000 */
     /* engine options (not in the reference) */
-    int32_t decoder_precision;  /* EV_PREC_F16 (default), EV_PREC_X3 (split precision) or EV_PREC_F32 (exact fp32 MFMA) */
+    int32_t decoder_precision;  /* EV_PREC_F16 (default), EV_PREC_X3 (split precision), EV_PREC_F32 (exact fp32 MFMA) or EV_PREC_MX
+                                   (split precision with the conv-FFN in the MX arithmetic, see vocoder_precision) */
     int32_t keep_stages;        /* !=0: keep every Appendix-C stage tap retrievable by ev_get_stage */
     int32_t token_rate_split;   /* 1 (default): fp32 token-rate GEMMs as 3 fp16 MFMAs on hi/lo splits (fp32-level accuracy,
                                    ~4x faster); 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */

@@ -624,7 +624,7 @@ class _PlaneSet:
         self.M, self.C, self.R = M, Cc, R
         self.h = torch.full((R, Cc), 3.0, device="cuda", dtype=torch.float16)
         self.q4 = [torch.full((R, Cc // 2), 0x77, device="cuda", dtype=torch.uint8) for _ in range(2)]
-        self.qs = [torch.full((Cc // 128, R, 4), 130, device="cuda", dtype=torch.uint8) for _ in range(2)]
+        self.qs = [torch.full((max(1, Cc // 128), R, 4), 130, device="cuda", dtype=torch.uint8) for _ in range(2)]
 
     def out_fields(self, d, slope):
         d.mxo_h = self.h[PAD:].data_ptr()
@@ -871,3 +871,96 @@ def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
     assert _rel(got, res["emu"]) < 5e-5, (k, dil, _rel(got, res["emu"]))
     assert _rel(got, res["exact"]) < 2e-4, (k, dil, _rel(got, res["exact"]))
     assert _rel(res["emu"], res["exact"]) > 1e-6
+
+
+@pytest.mark.parametrize("k,dil,mode,M", [(3, 1, "conv1", 256 * 3), (3, 5, "conv2acc", 256 * 8), (7, 3, "conv1", 256 * 9), (7, 1, "conv2", 256 * 17),
+                                          (11, 5, "conv1", 256 * 8), (11, 1, "conv2acc", 256 * 5), (3, 1, "up", 256 * 8)])
+def test_conv_c64_mx(lib, k, dil, mode, M):
+    """conv_c64_mx_kernel (ev_conv64_mx.h): the stage-2 convs (C = 64) in the MX arithmetic on plane sets -- two taps per fp4 MFMA, output
+    channels split over two work items; tile counts that are / are not multiples of 8 (padded work items must store nothing, also with
+    the in-place accumulate).  The input plane set comes from the host quantiser (mxfp4.py); fp64 references: the same arithmetic (tight) and
+    the exact conv (the MX error level).  Outputs: fp32 rows and / or the plane set of lrelu(result), which must equal the host quantiser
+    applied to the fp32 rows bit for bit."""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(500 + k + dil + M)
+    Cc = 64
+    R = M + 2 * PAD
+    full = torch.randn(R, Cc) * torch.exp(0.7 * torch.randn(R, 1))
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
+    valid[:2] = 0
+    valid[40:43] = 0
+    vrow = valid.repeat_interleave(8).bool()
+    ah, qah, qal, (h16, ch, cl, sh, sl) = _mx_act_parts(full)
+    s4 = lambda sb: np.concatenate([sb, np.ones((R, 2), np.uint8)], 1)        # noqa: E731  [rows][4 B], two bytes used
+    d_h = torch.from_numpy(h16).cuda()
+    d_q = [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in (ch, cl)]
+    d_s = [torch.from_numpy(s4(sb)).cuda() for sb in (sh, sl)]
+    w = torch.randn(Cc, Cc, k) / math.sqrt(Cc * k)
+    bias = torch.randn(Cc, device="cuda") * 0.1
+    wg = w.permute(0, 2, 1).contiguous().numpy()
+    planes = mxfp4.pack_c64_weight_planes(wg)
+    ql, qh = mxfp4.c64_weight_planes_dequant(planes, k)
+    hi = wg.astype(np.float16)
+    lo16 = ((wg - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    t64 = lambda z: torch.from_numpy(np.asarray(z, np.float64))          # noqa: E731
+    whd, wql, wqh, we = t64(hi), t64(ql), t64(qh), t64(wg)
+    d_hi, d_lo, d_mx = torch.from_numpy(hi).cuda(), torch.from_numpy(lo16).cuda(), torch.from_numpy(planes).cuda()
+    res = torch.randn(M, Cc, device="cuda")
+    acc = torch.randn(M, Cc, device="cuda")
+    want32 = mode != "conv1"                                            # conv1 of a pair writes its result as planes only
+    out = acc.clone() if mode == "conv2acc" else torch.full((M, Cc), 7.0, device="cuda")
+    ps = _PlaneSet(M, Cc)                                               # (its scale planes: [1][rows][4])
+    d = _ffi.ev_conv_gemm_desc()
+    d.dtype, d.A, d.lda, d.W, d.W_lo, d.W_mx = 3, d_h[PAD:].data_ptr(), Cc, d_hi.data_ptr(), d_lo.data_ptr(), d_mx.data_ptr()
+    d.mx_x4[0], d.mx_x4[1] = d_q[0][PAD:].data_ptr(), d_q[1][PAD:].data_ptr()
+    d.mx_xs[0], d.mx_xs[1], d.mx_xs_stride = d_s[0][PAD:].data_ptr(), d_s[1][PAD:].data_ptr(), R * 4
+    d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), M, Cc, Cc, k, dil, (k - 1) // 2, 1.0
+    d.row_valid, d.valid_shift = valid.data_ptr(), 3
+    if mode == "conv1":
+        d.act, d.act_slope = 3, 0.1
+    if mode.startswith("conv2"):
+        d.res, d.res_dtype, d.ldres, d.out_scale = res.data_ptr(), 1, Cc, 1.0 / 3.0
+        if mode == "conv2acc":
+            d.acc32, d.ldacc = out.data_ptr(), Cc
+    if want32:
+        d.out32 = out.data_ptr()
+    d.ldo = Cc
+    planes_out = mode in ("conv1", "conv2")
+    if planes_out:
+        ps.out_fields(d, 1.0 if mode == "conv1" else 0.1)
+        d.mxo_logC = 6
+    _launch(lib, d)
+    h = dil * (k - 1) // 2
+    rows = slice(PAD - h, PAD + M + h)
+    refs = {"emu": _conv64(ah[rows], whd, dil, k) + _conv64(qah[rows], wql, dil, k) + _conv64(qal[rows], wqh, dil, k),
+            "exact": _conv64(full.double()[rows], we, dil, k)}
+    vr = vrow.cpu()
+    for name in refs:
+        y = refs[name] + bias.double().cpu()
+        if mode == "conv1":
+            y = _lrelu(y, 0.1)
+        if mode.startswith("conv2"):
+            y = (y + res.double().cpu()) / 3.0 + (acc.double().cpu() if mode == "conv2acc" else 0.0)
+        y[~vr] = 0
+        refs[name] = y
+    if want32:
+        got = out.cpu().double()
+        assert float(out[~vrow].abs().max()) == 0.0
+        assert _rel(got, refs["emu"]) < 2e-6, (k, dil, mode, _rel(got, refs["emu"]))
+        assert _rel(got, refs["exact"]) < 1.5e-4, (k, dil, mode, _rel(got, refs["exact"]))
+    if planes_out:
+        gh = ps.h[PAD:PAD + M].float().cpu()
+        gq = [mxfp4.dequantize(ps.q4[i][PAD:PAD + M].cpu().numpy(), ps.qs[i][0, PAD:PAD + M, :2].cpu().numpy(), 32) for i in range(2)]
+        if want32:              # the planes are the host quantiser applied to lrelu(out32, 0.1), bit for bit
+            _, _, _, (h16o, cho, clo, sho, slo) = _mx_act_parts(_lrelu(out.cpu(), 0.1))
+            assert np.array_equal(ps.h[PAD:PAD + M].cpu().numpy().view(np.uint16), h16o.view(np.uint16))
+            for i, (codes, sb) in enumerate(((cho, sho), (clo, slo))):
+                assert np.array_equal(ps.q4[i][PAD:PAD + M].cpu().numpy(), codes), i
+                assert np.array_equal(ps.qs[i][0, PAD:PAD + M, :2].cpu().numpy(), sb), i
+        else:                   # planes only: hi + Q(lo) reproduces the conv's result to the fp4 step of the remainder (2^-11 x 0.25)
+            rec = gh.double() + torch.from_numpy(gq[1]).double()
+            assert _rel(rec, refs["emu"]) < 1e-4, (k, dil, mode, _rel(rec, refs["emu"]))
+            assert _rel(gh.double(), refs["emu"]) < 6e-4 and not ps.h[PAD:PAD + M].cpu().numpy()[~vr.numpy()].any()
+    assert _rel(refs["emu"], refs["exact"]) > 1e-6
