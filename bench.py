@@ -210,7 +210,7 @@ def roofline_block(eng, work, torch, strict=None):
         tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
         if os.path.exists(tpath) and work.mode == "am_vocoder" and B == 32:
             t = json.load(open(tpath))
-            t = t.get(mode, t if mode == "f16" and "hbm_bytes_per_launch" in t else {})
+            t = t.get(mode, t if mode == "f16" and "hbm_bytes_per_launch" in t else {})          # one entry per precision mode (tools/profile_summary.py)
             traffic = t.get("hbm_bytes_per_launch")
             tnote = "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json"
         roof = dict(bound="mfma", kernel=desc + " (HiFi-GAN Conv1d / ConvTranspose1d launches of this family)",
@@ -277,6 +277,81 @@ def bench_style(args, torch):
     print(json.dumps(line))
 
 
+def bench_pipeline(args, torch):
+    """--mode pipeline (not a BASELINE config): the HOST pipeline end to end at B = 32 -- text line -> G2P -> phoneme ids,
+    prompt + content -> WordPiece ids -> SimBERT on the device, ev_synthesize with host inputs (mx precision), int16 waveform back on the
+    host -- one process, one GPU, so that the limiter of the 8-GPU target (host feeding) is a measured number.
+    Stand-ins for what is not in the image: tools/g2p_standin.py (the reference's English lexicon path at realistic cost), a WordPiece
+    vocabulary built from the same lexicon, seeded synthetic SimBERT / generator weights."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from g2p_standin import make_g2p, make_lexicon, make_text, token_table
+    from emotivoice_amd import _ffi
+    from emotivoice_amd.engine import EVEngine
+    from emotivoice_amd.frontend_pool import FrontendPool
+    from emotivoice_amd.packer import pack_bert_state_dict, pack_state_dict
+    from emotivoice_amd.synthetic import synth_bert_state_dict, synth_state_dict
+    from emotivoice_amd.wordpiece import WordPieceTokenizer
+    nb = args.batch or 32
+    lex = make_lexicon()
+    g2p = make_g2p(lex)
+    tok2id = token_table()
+    texts = make_text(lex, nb * (args.steps + args.warmup), words_per_line=14)
+    prompts = ["happy", "sad", "angry", "excited"]
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", ",", "."] + list(lex.keys())[:13000] + prompts
+        f.write("\n".join(vocab) + "\n")
+        vpath = f.name
+    tok = WordPieceTokenizer(vpath)
+    pool = FrontendPool(g2p, workers=args.frontend_workers) if args.frontend_workers > 1 else None      # forks BEFORE the HIP runtime starts
+    eng = EVEngine(device_id=0, precision=args.precision)
+    eng.load_blob(*pack_state_dict(synth_state_dict(0, "parity")))
+    bblob, _, bcfg = pack_bert_state_dict(synth_bert_state_dict(0))
+    eng.style_load(bblob, bcfg)
+    parts = dict(g2p=0.0, ids=0.0, tokenize=0.0, simbert=0.0, synth=0.0, d2h=0.0)
+    frames = utts = 0
+    t_all = None
+    for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            torch.cuda.synchronize()
+            parts = {k: 0.0 for k in parts}
+            frames = utts = 0
+            t_all = time.perf_counter()
+        lines = texts[step * nb:(step + 1) * nb]
+        t0 = time.perf_counter()
+        phon = pool.map(lines) if pool is not None else [g2p(t) for t in lines]
+        t1 = time.perf_counter()
+        ling = [np.array([tok2id[x] % 502 for x in ph.split()], np.int64) for ph in phon]
+        t2 = time.perf_counter()
+        ids = [np.asarray(tok.encode(t, max_length=512), np.int64) for t in [prompts[i % 4] for i in range(nb)] + lines]
+        t3 = time.perf_counter()
+        emb = eng.style_embed(ids)                                   # (2 nb, 768): prompt rows, then content rows
+        t4 = time.perf_counter()
+        cu = np.zeros(nb + 1, np.int32); cu[1:] = np.cumsum([len(x) for x in ling])
+        flat = np.ascontiguousarray(np.concatenate(ling)); spk = np.arange(nb, dtype=np.int64) % 2014
+        style, content = np.ascontiguousarray(emb[:nb]), np.ascontiguousarray(emb[nb:])
+        res = eng.synthesize_raw(nb, flat.ctypes.data, cu, spk.ctypes.data, style.ctypes.data, content.ctypes.data, 1.0, _ffi.EV_FLAG_WANT_INT16)
+        t5 = time.perf_counter()
+        wav = eng.d2h(res.wav_i16, (res.total_samples,), np.int16)
+        t6 = time.perf_counter()
+        for k, v in zip(parts, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+            parts[k] += v
+        frames += int(res.total_frames); utts += nb
+    dt = time.perf_counter() - t_all
+    if pool is not None:
+        pool.close()
+    os.unlink(vpath)
+    assert wav.size == int(res.total_samples) and np.abs(wav).max() > 0
+    print(json.dumps({
+        "metric": "host_pipeline_utterances_per_sec", "value": round(utts / dt, 1), "unit": "utterances/s", "mel_frames_per_sec": round(frames / dt, 1),
+        "x_realtime": round(frames / dt * 256 / 16000, 1), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "data": "synthetic", "precision": args.precision,
+        "config": {"workload": "text line -> int16 wav on the host, B = %d lines of 14 words (~%d phonemes) per step, one process" % (nb, int(np.mean([len(x) for x in ling]))),
+                   "frontend_workers": args.frontend_workers},
+        "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in parts.items()},
+        "note": "g2p / ids / tokenize are pure host time; simbert, synth and d2h include their device time (the calls are synchronous)"}))
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -315,7 +390,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", default="am_vocoder", choices=["am_vocoder", "ragged", "vocoder", "style"])
+    ap.add_argument("--mode", default="am_vocoder", choices=["am_vocoder", "ragged", "vocoder", "style", "pipeline"])
+    ap.add_argument("--frontend-workers", type=int, default=1, help="--mode pipeline: G2P worker processes (1 = in the synthesis process, like the reference)")
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU per (sub-)batch (default: 32 / 256 / 128 by mode)")
     ap.add_argument("--sub-batches", type=int, default=0, help="am_vocoder: sub-batches per step (default 1 at N = 1, 8 at N > 1 = configs[3])")
     ap.add_argument("--phonemes", type=int, default=256)
@@ -355,6 +431,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if args.mode == "style":
         return bench_style(args, torch)
+    if args.mode == "pipeline":
+        return bench_pipeline(args, torch)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -23,6 +23,7 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 N_DEC = 17          # decoder launches of the same template in front of the vocoder's (4 layers x 4 GEMMs + to_mel)
+N_DEC_MX = 8        # "mx" precision: the decoder's conv-FFN launches (4 layers x 2) of conv_gemm_mx_kernel in front of the generator's
 GIB = float(1 << 30)
 
 
@@ -51,6 +52,13 @@ FAMILIES = {
     "attention_mfma_f16": lambda f: [r for r in f if "attention_mfma_kernel" in r["Kernel_Name"]],
     "conv_gemm_split_token_rate": lambda f: [r for r in f if "conv_gemm_split_kernel" in r["Kernel_Name"] or "conv_gemm_x3_kernel" in r["Kernel_Name"]],
     "layernorm": lambda f: [r for r in f if "layernorm_kernel" in r["Kernel_Name"]],
+    # round 3, "mx" precision (bench.py's default): the generator's three MX kernels, the decoder's conv-FFN on the same conv-GEMM kernel
+    "conv_gemm_mx_vocoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][N_DEC_MX:],
+    "conv_gemm_mx_decoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][:N_DEC_MX],
+    "conv_c64_mx": lambda f: [r for r in f if "conv_c64_mx_kernel" in r["Kernel_Name"]],
+    "resblock_pair_c32_mx": lambda f: [r for r in f if "resblock_pair_c32_mx_kernel" in r["Kernel_Name"]],
+    "mx_planes_kernel": lambda f: [r for r in f if "mx_planes_kernel" in r["Kernel_Name"]],
+    "attention_mfma_f32": lambda f: [r for r in f if "attention_mfma_f32_kernel" in r["Kernel_Name"]],
 }
 
 
@@ -110,6 +118,7 @@ def calibration():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
+    ap.add_argument("--mode", default="mx", choices=["mx", "f16"], help="precision the profiled bench.py ran in (its default is mx)")
     args = ap.parse_args()
     pdir = os.path.join(ROOT, "profiles")
     ks = find_csv("prof", "kernel_stats.csv")
@@ -119,7 +128,7 @@ def main():
     kt = find_csv("prof", "kernel_trace.csv")
     if kt:
         for f in forwards(list(csv.DictReader(open(kt)))):
-            g = FAMILIES["conv_gemm_f16_vocoder"](f)
+            g = FAMILIES["conv_gemm_mx_vocoder" if args.mode == "mx" else "conv_gemm_f16_vocoder"](f)
             if g:
                 avgs.append(sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in g) / len(g) / 1e6)
         print("rocprof kernel trace: avg duration of the vocoder conv_gemm launches per B=32 forward (ms):", ", ".join("%.4f" % a for a in avgs))
@@ -138,7 +147,9 @@ def main():
             fam[name] = dict(launches=ff[name]["launches"], fetch_size_kb_raw=ff[name]["FETCH_SIZE"], write_size_kb_raw=fw_[name]["WRITE_SIZE"],
                              hbm_bytes_per_forward=fb + wb, hbm_bytes_per_launch=(fb + wb) / ff[name]["launches"])
         frames = 32768
-        voc = sum(fam[k]["hbm_bytes_per_forward"] for k in ("conv_gemm_f16_vocoder", "resblock_pair_c32_c64") if k in fam)
+        voc = sum(fam[k]["hbm_bytes_per_forward"] for k in ("conv_gemm_f16_vocoder", "resblock_pair_c32_c64", "conv_gemm_mx_vocoder", "conv_c64_mx",
+                                                            "resblock_pair_c32_mx", "mx_planes_kernel") if k in fam)
+        dom = "conv_gemm_mx_vocoder" if args.mode == "mx" else "conv_gemm_f16_vocoder"
         doc = {
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 1 --warmup 1 --cpu-utts 0 --no-other-precision`, the B=32 x 1024-frame forward",
             "correction": dict(fetch_factor=f_corr, write_factor=w_corr, calibration=cal,
@@ -146,11 +157,17 @@ def main():
                                     "(tools/pmc_calibrate.py); without a calibration run: FETCH_SIZE x 2 (MI355X_MICROARCH.md section HBM), WRITE_SIZE x 1"),
             "families": fam, "frames": frames, "vocoder_hbm_bytes_per_frame": voc / frames,
             "algorithmic_contract_bytes_per_frame": 2026000.0,
-            "hbm_bytes_per_launch": fam.get("conv_gemm_f16_vocoder", {}).get("hbm_bytes_per_launch"),
-            "rocprof_avg_launch_ms_per_forward": avgs,
+            "hbm_bytes_per_launch": fam.get(dom, {}).get("hbm_bytes_per_launch"),
+            "rocprof_avg_launch_ms_per_forward": avgs, "mode": args.mode, "dominant_family": dom,
         }
-        for name in (args.tag + "_hbm_traffic.json", "latest_hbm_traffic.json"):
-            json.dump(doc, open(os.path.join(pdir, name), "w"), indent=1)
+        json.dump(doc, open(os.path.join(pdir, args.tag + "_hbm_traffic.json"), "w"), indent=1)
+        # latest_hbm_traffic.json: one entry per precision mode (bench.py reads roofline.traffic of its mode from it)
+        lp = os.path.join(pdir, "latest_hbm_traffic.json")
+        latest = json.load(open(lp)) if os.path.exists(lp) else {}
+        if "families" in latest and "f16" not in latest:          # round-2 layout: the whole file was the fp16 measurement
+            latest = {"f16": latest}
+        latest[args.mode] = doc
+        json.dump(latest, open(lp, "w"), indent=1)
         print(json.dumps({k: v for k, v in doc.items() if k not in ("families",)}, indent=1))
     sq = {}
     ps = find_csv("pmc_sq", "counter_collection.csv")
@@ -184,7 +201,7 @@ def main():
                               "sums over the launches of each kernel family", families=sq), open(os.path.join(pdir, args.tag + "_sq_counters.json"), "w"), indent=1)
         for k, v in sq.items():
             print(k, {a: (round(b, 4) if isinstance(b, float) and b < 10 else b) for a, b in v.items() if "frac" in a or "over" in a})
-    for src, dst in (("launches.json", "_launches.json"), ("launches.json.strict", "_launches_strict.json")):
+    for src, dst in (("launches.json", "_launches_f16.json"), ("launches.json.mx", "_launches_mx.json"), ("launches.json.x3", "_launches_strict.json")):
         p = os.path.join(OUT, src)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(pdir, args.tag + dst))
