@@ -32,8 +32,10 @@ class _DevArray:
 class JETSGeneratorHIP:
     def __init__(self, config=None, decoder_precision: Optional[str] = None, keep_stages: bool = False, pe_len: int = 4096,
                  precision: Optional[str] = None, vocoder_precision: Optional[str] = None):
-        """``precision``: "fast" (fp16 MFMA operands on the frame-rate path) or "strict" (split precision, fp32-class parity with
-        the reference module: ~1e-6 relative L2 on mel and waveform); default "fast".  See engine.resolve_precision."""
+        """``precision``: "mx" (the contract mode: waveform within 1e-3 of the reference on every fixture; one fp16 MFMA + two
+        block-scaled fp4 MFMAs per product), "fast" (fp16 MFMA operands and activations: 2x the speed, 2.4e-3 on zero-mean audio) or
+        "strict" (split precision, ~1e-6); default "fast" for backward compatibility of the constructor, the CLIs default to "mx".
+        See engine.resolve_precision."""
         self.config = config
         self.shapes: EVShapes = from_reference_config(config)
         self.segment_size = self.shapes.segment_size

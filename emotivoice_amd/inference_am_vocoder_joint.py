@@ -123,7 +123,8 @@ def main(argv=None):
     p.add_argument("--embeddings", default=None, help=".npz with 'style' and 'content' (n_lines, 768) arrays (the SimBERT pooled outputs)")
     p.add_argument("--batch", type=int, default=32)
     p.add_argument("--device", default="cuda:0")
-    p.add_argument("--precision", default="strict", choices=["fast", "strict"])
+    p.add_argument("--precision", default="mx", choices=["mx", "fast", "strict"],
+                   help="mx: the contract mode (waveform within 1e-3 of the reference, fp4 cross terms); fast: fp16; strict: split precision")
     p.add_argument("--synthetic-weights", action="store_true",
                    help="no checkpoint directory: synthesise with the seeded synthetic checkpoint (named 'synthetic')")
     args = p.parse_args(argv)

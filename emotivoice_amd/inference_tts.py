@@ -204,7 +204,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-n", "--num_thread", type=str, required=False, default="1")
     # not in the reference:
     p.add_argument("--batch", type=int, default=32)
-    p.add_argument("--precision", default="strict", choices=["fast", "strict"])
+    p.add_argument("--precision", default="mx", choices=["mx", "fast", "strict"],
+                   help="mx: the contract mode (waveform within 1e-3 of the reference, fp4 cross terms); fast: fp16; strict: split precision")
     p.add_argument("--g2p", default=None, help="pkg.module:function mapping a content line to a space-separated phoneme string")
     p.add_argument("--frontend_workers", type=int, default=1, help="fork-pool workers for the G2P of a process")
     p.add_argument("--phoneme-input", action="store_true", help="the lines already are space-separated phoneme tokens")

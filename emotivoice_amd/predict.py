@@ -22,7 +22,7 @@ MAX_WAV_VALUE = 32768.0          # models/hifigan/get_vocoder.py (imported by th
 class Predictor:
     def __init__(self, token_list_path: str, speaker2id_path: str, output_directory: str = ".", conf=None,
                  device: str = "cuda:0", style_embedder: Optional[Callable[[str], np.ndarray]] = None,
-                 g2p: Optional[dict] = None, precision: str = "strict"):
+                 g2p: Optional[dict] = None, precision: str = "mx"):
         """``g2p``: {"English": fn(text) -> phoneme string, "Chinese": fn} -- the reference's frontend_en.g2p_en / frontend_cn.g2p_cn
         (jieba / pypinyin / g2p_en are host-side third-party packages outside the hot path; pass them in when installed)."""
         self.conf = conf
