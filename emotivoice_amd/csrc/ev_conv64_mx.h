@@ -37,7 +37,7 @@ struct Conv64MxGeom {
 template <int K, int MODE>
 __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParams p) {
     using G = Conv64MxGeom<K>;
-    constexpr int NB = G::NB, KG = G::KG, KP = G::KP, XROWS = G::XROWS, EPITCH = G::EPITCH;
+    constexpr int NB = G::NB, KG = G::KG, XROWS = G::XROWS, EPITCH = G::EPITCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Wh = smem + G::OFF_WH;        // [chunk][tap * 32 + co][64 B] swizzled
     char* const Wq = smem + G::OFF_WQ;        // [plane][tap * 32 + co][32 B], halves swapped where (co >> 3) & 1
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
         coff[j] = (unsigned)min(crow[j], last_row) * 32u + (tid & 1) * 16u;
     }
     const int chalf = tid & 1;
-    const int spl = min(tid / 80, 1), srow = (tid % 80) * 4;
+    // (threads >= 160 duplicate unit 159: a load whose result some lanes never consume leaves a pending write on its registers, and the next
+    // item's request for them then waits -- vmcnt is in order -- for every store issued since: 2.5 k cycles per item in the first version)
+    const int su = min(tid, 159);
+    const int spl = su / 80, srow = (su % 80) * 4;
     const unsigned soff = (unsigned)srow * 4u;
     const char* const hbase = reinterpret_cast<const char*>(p.A);
     const char* const cbase0 = reinterpret_cast<const char*>(p.mx_x4[0]);
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
         }                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                      \
             *reinterpret_cast<u32x4*>(Xq + cpl[j] * XROWS * 32 + crow[j] * 32 + ((chalf ^ ((crow[j] >> 3) & 1)) << 4)) = xc[j]; \
-        if (tid < 160) *reinterpret_cast<u32x4*>(Xsc + spl * XROWS * 4 + srow * 4) = xs4;                  \
+        *reinterpret_cast<u32x4*>(Xsc + spl * XROWS * 4 + srow * 4) = xs4;                                 \
     }
 
     EV_C64_GLOAD(EV_C64_TILE(item))
@@ -244,11 +247,14 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + er * EPITCH + eg * 32 + 16);
             vv[it][0] = f32x2{v0[0], v0[1]}; vv[it][1] = f32x2{v0[2], v0[3]}; vv[it][2] = f32x2{v1[0], v1[1]}; vv[it][3] = f32x2{v1[2], v1[3]};
         }
+        // ... then ALL the arithmetic (it consumes the residual / accumulate-in rows: once a store has been issued, a wait for an older load
+        // is a wait for that store too, and with a run-time number of stores per row group it is vmcnt(0)), and only then the stores
+        uint4 pho[2];
+        unsigned pch[2], pcl[2], pbh[2], pbl[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {          // ... then the arithmetic of both row groups: two independent chains for the scheduler
-            const long t = m0 + wave * 32 + it * 16 + er;
+        for (int it = 0; it < 2; ++it) {
             const bool valid = (vmask & (erbit << (it * 16))) != 0u;
-            f32x2 v[4] = {vv[it][0], vv[it][1], vv[it][2], vv[it][3]};
+            f32x2* v = vv[it];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] += bv[q];
             if (act_lrelu) {
@@ -265,25 +271,32 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
                 v[0] += f32x2{accin[it][0].x, accin[it][0].y}; v[1] += f32x2{accin[it][0].z, accin[it][0].w};
                 v[2] += f32x2{accin[it][1].x, accin[it][1].y}; v[3] += f32x2{accin[it][1].z, accin[it][1].w};
             }
-            if (item_ok && o32 && !(abl & 2)) {
-                float* op = o32 + t * p.ldo + eco;
-                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q][0] = valid ? v[q][0] : 0.f; v[q][1] = valid ? v[q][1] : 0.f; }
             if (has_planes && !(abl & 32)) {            // the next conv's operand: its leaky-relu, then the planes (this quad = one 32-channel block of the row)
                 f32x2 am[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { am[q] = lrelu2(v[q], mxo_slope2); am[q][0] = valid ? am[q][0] : 0.f; am[q][1] = valid ? am[q][1] : 0.f; }
-                uint4 ho; unsigned ch, cl, bh, bl;
-                mx_quant8(am, ho, ch, cl, bh, bl);
-                if (item_ok && !(abl & 1)) {
-                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + (t * 64 + eco) * 2) = ho;
-                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + t * 32 + (n0 >> 5) * 16 + eg * 4) = ch;
-                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + t * 32 + (n0 >> 5) * 16 + eg * 4) = cl;
-                    if (eg == 0) {
-                        reinterpret_cast<uint8_t*>(p.mxo_qs[0])[t * 4 + (n0 >> 5)] = (uint8_t)bh;
-                        reinterpret_cast<uint8_t*>(p.mxo_qs[1])[t * 4 + (n0 >> 5)] = (uint8_t)bl;
-                    }
+                for (int q = 0; q < 4; ++q) am[q] = lrelu2(v[q], mxo_slope2);
+                mx_quant8(am, pho[it], pch[it], pcl[it], pbh[it], pbl[it]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const long t = m0 + wave * 32 + it * 16 + er;
+            const f32x2* v = vv[it];
+            if (item_ok && o32 && !(abl & 2)) {
+                float* op = o32 + t * p.ldo + eco;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
+            }
+            if (has_planes && item_ok && !(abl & 33)) {
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + (t * 64 + eco) * 2) = pho[it];
+                *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + t * 32 + (n0 >> 5) * 16 + eg * 4) = pch[it];
+                *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + t * 32 + (n0 >> 5) * 16 + eg * 4) = pcl[it];
+                if (eg == 0) {
+                    reinterpret_cast<uint8_t*>(p.mxo_qs[0])[t * 4 + (n0 >> 5)] = (uint8_t)pbh[it];
+                    reinterpret_cast<uint8_t*>(p.mxo_qs[1])[t * 4 + (n0 >> 5)] = (uint8_t)pbl[it];
                 }
             }
         }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
     const int m0 = (bid / nN) * BM, nt = bid % nN, n0 = nt * 128;
-    const int nkc16 = p.K >> 5, nkc4 = p.K >> 7, nq = nkc16 + 2 * nkc4;
+    const int nkc16 = p.K >> 5, nkc4 = p.K >> 7;
     const unsigned K2 = (unsigned)p.K >> 1;                // row / tap pitch of a fp4 plane in bytes; the fp16 planes' is 4 x that
     const unsigned wrp4 = K2 * TAPS;
     const int row0 = m0 - p.center * p.dil;                // first slab row (negative for the first tile: slack rows)
@@ -155,11 +155,9 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const char* const xb4l = uniform_ptr(reinterpret_cast<const char*>(p.mx_x4[1]) + (long)row0 * (long)K2);
     const char* const wb16 = uniform_ptr(reinterpret_cast<const char*>(p.W) + (long)n0 * (long)(4 * wrp4));
     const char* const wb4l = uniform_ptr(wmx + (long)n0 * (long)wrp4);
-    const char* const wb4h = uniform_ptr(wmx + nw4 + (long)n0 * (long)wrp4);
     const char* const sxh = uniform_ptr(reinterpret_cast<const char*>(p.mx_xs[0]) + (long)row0a * 4);
     const char* const sxl = uniform_ptr(reinterpret_cast<const char*>(p.mx_xs[1]) + (long)row0a * 4);
     const char* const swl = uniform_ptr(wmx + 2 * nw4 + (size_t)nt * nkc4 * TAPS * 128);
-    const char* const swh = uniform_ptr(wmx + 2 * nw4 + nws + (size_t)nt * nkc4 * TAPS * 128);
     const unsigned xs_stride = p.mx_xs_stride;
 
     // Operand sources of a chunk are plain scalar arithmetic on these bases (two-way uniform selects at most: a lambda returning a struct

@@ -96,6 +96,13 @@ def _engine(wmode, prec="fast", keep=True):
     return _CACHE[key]
 
 
+def _drop_engines(only_big=True):
+    """Close cached engines (their workspaces stay at the largest batch they have seen): tests that are about to run a BASELINE config at full
+    size in several precisions call this first -- three 128-mel workspaces on top of the cached ones exceeded the 288 GB in round 3."""
+    for key in [k for k in _CACHE if isinstance(k, tuple) and k[0] == "eng" and (not only_big or not k[3])]:
+        _CACHE.pop(key).close()
+
+
 def _oracle(wmode, utt, taps=None, durations=None, vocoder=True):
     from oracle import EVShapes, am_forward, jets_forward
     sd, _, _ = _weights(wmode)
@@ -401,6 +408,7 @@ def test_config3_ragged_256_every_utterance(gpu, prec):
     wav_idx = set([picks[0]] + list(range(1, 256, 17)))          # 16 utterances incl. the shortest
     rep = _compare_utterances(eng, "parity", utts, out, wav_idx, tol, tol, "config3_all/" + prec)
     assert rep["n"] == 256
+    _drop_engines()
 
 
 @pytest.mark.parametrize("prec", ["mx", "fast", "strict"])
@@ -411,6 +419,7 @@ def test_config5_vocoder_only_full_size(gpu, prec):
     for a GAN vocoder --: exact lengths, bounded finite audio, every mel's waveform bit-identical to the same mel anywhere else in the
     batch and vocoded alone (no cross-utterance leakage at any of the 4 upsampling stages)."""
     from oracle import EVShapes, hifigan_forward
+    _drop_engines()
     eng = _engine("parity_zdc", prec, keep=False)
     sd, _, _ = _weights("parity_zdc")
     rng = np.random.default_rng(9)
@@ -430,6 +439,7 @@ def test_config5_vocoder_only_full_size(gpu, prec):
     assert max(max(v) for v in errs.values()) < bound, errs
     solo = eng.vocoder([mels[3]])
     assert np.array_equal(solo["wav"], first[3])
+    _drop_engines()
 
 
 @pytest.mark.parametrize("prec", ["fast", "strict"])
