@@ -407,7 +407,10 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         if (prec == DT_F16) p.out16 = qkv.p; else p.out32 = (float*)qkv.p;
         if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         AttnParams ap{};
-        ap.qkv = qkv.p; ap.dtype = prec; ap.ld = 3 * C; ap.C = C; ap.heads = h->cfg.heads; ap.seq_off = rc.seq_off;
+        // decoder in the strict / mx modes: split-precision attention (three fp16 MFMAs per product); the token-rate encoder keeps exact fp32
+        const bool att_split = prec == DT_F32 && !strcmp(pre, "dec") && (h->cfg.decoder_precision == EV_PREC_X3 || h->cfg.decoder_precision == EV_PREC_MX) &&
+                               C / h->cfg.heads == 48 && !getenv("EV_ATTN_F32");
+        ap.qkv = qkv.p; ap.dtype = att_split ? (int)DT_F32S : prec; ap.ld = 3 * C; ap.C = C; ap.heads = h->cfg.heads; ap.seq_off = rc.seq_off;
         ap.seq_len = rc.seq_len; ap.B = rc.B; ap.max_len = rc.max_len; ap.out = ctx.p; ap.ldo = C;
         { KScope ks(h, (kn + "_attention").c_str(), 0, 0); launch_attention(ap, h->stream); }
         p = gemm_defaults();
@@ -1546,7 +1549,8 @@ int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const f
 int ev_op_attention(const void* qkv, int is_f16, int C, int heads, const int32_t* seq_off, const int32_t* seq_len, int B, int max_len,
                     void* out, void* stream) {
     AttnParams p{};
-    p.qkv = qkv; p.dtype = is_f16 ? DT_F16 : DT_F32; p.ld = 3 * C; p.C = C; p.heads = heads; p.seq_off = seq_off; p.seq_len = seq_len;
+    // is_f16 == 2: fp32 rows, split-precision products
+    p.qkv = qkv; p.dtype = is_f16 == 1 ? DT_F16 : (is_f16 == 2 ? DT_F32S : DT_F32); p.ld = 3 * C; p.C = C; p.heads = heads; p.seq_off = seq_off; p.seq_len = seq_len;
     p.B = B; p.max_len = max_len; p.out = out; p.ldo = C;
     launch_attention(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;

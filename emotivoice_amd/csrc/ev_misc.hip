@@ -567,7 +567,125 @@ __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParam
     }
 }
 
+// ---- split-precision MFMA flash attention (mel decoder in the strict / mx modes; round 3).  Same structure, operand permutation and online
+// softmax as attention_mfma_f32_kernel, but every product runs on the fp16 pipe as three MFMAs on hi / lo halves
+//     x = xh + 2^-11 xl,  xh = fp16(x),  xl = fp16((x - xh) 2^11):      a.b = ah.bh + 2^-11 (ah.bl + al.bh) + O(2^-22)
+// (the arithmetic of conv_gemm_split_kernel): v_mfma_f32_16x16x16_f16 holds FOUR consecutive reduction slots per lane, which are exactly the
+// four registers the fp32 kernel feeds to four 16x16x4 steps (qv[4 s .. 4 s + 3] / the keys 4 g + i of the P.V product), so the operands are
+// plain register packs.  Per 16-key tile: 9 + 9 fp16 MFMAs at the 16x rate instead of 12 + 12 fp32 ones; the exact-fp32 kernel stays for the
+// token-rate encoder (its output decides the bit-exact durations) and SimBERT.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const float* x, h4& hi, h4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        hi[i] = h;
+        lo[i] = (_Float16)((x[i] - (float)h) * 2048.0f);
+    }
+}
+template <int DK>
+__global__ __launch_bounds__(256) void attention_mfma_x3_kernel(const AttnParams p) {
+    static_assert(DK % 16 == 0, "d_k = 48: 3 reduction steps of 16, 3 output tiles of 16");
+    constexpr int NJ = DK / 4, ND = DK / 16, NC = NJ / 4, NS = DK / 16;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = p.seq_len[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    if (q0 >= len) return;
+    const int fr = lane & 15, g = lane >> 4;
+    const long row0 = p.seq_off[b];
+    const float* base = reinterpret_cast<const float*>(p.qkv);
+    const float scale = 1.0f / sqrtf((float)DK);
+    constexpr float LO = 1.0f / 2048.0f;
+
+    h4 qh[NS], ql[NS];
+    {
+        const int qi = min(q0 + fr, len - 1);
+        const float4* qp = reinterpret_cast<const float4*>(base + (row0 + qi) * p.ld + h * DK + g * NJ);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 t = qp[c];
+            const float x[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
+            split4(x, qh[c], ql[c]);
+        }
+    }
+    f4 oh[ND], ox[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) { oh[dt] = f4{0.f, 0.f, 0.f, 0.f}; ox[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
+    float m = -INFINITY, l = 0.f;
+    float kv[NJ], vv[ND][4];
+    const int ntile = (len + 15) >> 4;
+#define EV_ATX_LOAD(KT)                                                                                        \
+    {                                                                                                          \
+        const int kr_ = min((KT) * 16 + fr, len - 1);                                                          \
+        const float4* kp_ = reinterpret_cast<const float4*>(base + (row0 + kr_) * p.ld + p.C + h * DK + g * NJ); \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c) { const float4 t = kp_[c]; kv[4 * c] = t.x; kv[4 * c + 1] = t.y; kv[4 * c + 2] = t.z; kv[4 * c + 3] = t.w; } \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+            const float* vp_ = base + (row0 + min((KT) * 16 + 4 * g + i, len - 1)) * p.ld + 2 * p.C + h * DK + fr; \
+            _Pragma("unroll") for (int dt = 0; dt < ND; ++dt) vv[dt][i] = vp_[dt * 16];                          \
+        }                                                                                                      \
+    }
+    EV_ATX_LOAD(0)
+    for (int kt = 0; kt < ntile; ++kt) {
+        f4 sh = f4{0.f, 0.f, 0.f, 0.f}, sx = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            h4 kh, kl;
+            split4(kv + 4 * c, kh, kl);
+            sh = __builtin_amdgcn_mfma_f32_16x16x16f16(kh, qh[c], sh, 0, 0, 0);
+            sx = __builtin_amdgcn_mfma_f32_16x16x16f16(kh, ql[c], sx, 0, 0, 0);
+            sx = __builtin_amdgcn_mfma_f32_16x16x16f16(kl, qh[c], sx, 0, 0, 0);
+        }
+        h4 vh[ND], vl[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) split4(vv[dt], vh[dt], vl[dt]);
+        if (kt + 1 < ntile) EV_ATX_LOAD(kt + 1)          // next tile's K / V rows arrive under this tile's softmax and PV
+        float sc[4];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = (kt * 16 + 4 * g + i < len) ? sh[i] + sx[i] * LO : -INFINITY;
+            cm = fmaxf(cm, sc[i]);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 16));
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float alpha = expf(m - mn);            // m = -inf on the first tile -> 0
+        m = mn;
+        float pr[4];
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pr[i] = expf(sc[i] - mn); ps += pr[i]; }
+        l = l * alpha + ps;
+        h4 ph, pl;
+        split4(pr, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            oh[dt] *= alpha; ox[dt] *= alpha;
+            oh[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[dt], ph, oh[dt], 0, 0, 0);
+            ox[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[dt], pl, ox[dt], 0, 0, 0);
+            ox[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vl[dt], ph, ox[dt], 0, 0, 0);
+        }
+    }
+#undef EV_ATX_LOAD
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (q0 + fr < len) {
+        const float inv = 1.0f / l;
+        float* op = reinterpret_cast<float*>(p.out) + (row0 + q0 + fr) * p.ldo + h * DK + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const f4 o = oh[dt] + ox[dt] * LO;
+            *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        }
+    }
+}
+
 void launch_attention(const AttnParams& p, hipStream_t s) {
+    if (p.dtype == DT_F32S && p.C / p.heads == 48) {          // fp32 rows, split-precision products (decoder, strict / mx modes)
+        hipLaunchKernelGGL((attention_mfma_x3_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+        return;
+    }
     if (p.dtype == DT_F16) {
         static const bool valu = getenv("EV_ATTN_VALU") != nullptr;     // A/B switch: fp32-math VALU kernel on fp16 inputs
         if (!valu) {

@@ -81,7 +81,9 @@ int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const f
                     const uint8_t* row_valid, void* out16, float* out32, const float* dot_w, float dot_b,
                     float* dot_out, void* hip_stream);
 
-/* Multi-head self-attention restricted to each utterance's rows (reference modules/encoder.py:72-109). */
+/* Multi-head self-attention restricted to each utterance's rows (reference modules/encoder.py:72-109).
+ * is_f16: 1 = fp16 rows (fp16 MFMA flash kernel), 0 = fp32 rows, exact fp32 MFMA products, 2 = fp32 rows, split-precision products
+ * (three fp16 MFMAs each: the mel decoder in the strict / mx modes). */
 int ev_op_attention(const void* qkv, int is_f16, int C, int heads, const int32_t* seq_off, const int32_t* seq_len,
                     int B, int max_len, void* out, void* hip_stream);
 
