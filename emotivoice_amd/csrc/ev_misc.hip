@@ -681,9 +681,142 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_kernel(const AttnParams
     }
 }
 
+// ---- the same arithmetic with the K / V tiles shared through LDS.  In the kernel above every wave fetches its own copy of each 16-key tile
+// (V as twelve strided dword loads per lane) and splits it itself: 2.6 ms for the four decoder layers at B = 32 x 1024 frames, memory-instruction
+// bound (the MFMAs are 5 % of it).  Here a block of four waves (64 queries) stages 32 keys at a time: 768 float4 loads, split ONCE into fp16
+// hi / lo planes in the operand layouts -- K row-major [key][48] (pitch 104 B: conflict-free 8-byte fragment reads), V transposed [d][key]
+// (pitch 72 B) --, double-buffered, one barrier per stage; a wave's fragments are twelve ds_read_b64 per 16 keys.
+template <int DK>
+__global__ __launch_bounds__(256) void attention_mfma_x3_lds_kernel(const AttnParams p) {
+    static_assert(DK == 48, "d_k = 48: 12 float4 per row, 3 reduction steps of 16, 3 output tiles of 16");
+    constexpr int NS = DK / 16, ND = DK / 16, KT = 32, KP = 104, VP = 72;
+    constexpr int KB = KT * KP, VB = DK * VP, STAGE = 2 * KB + 2 * VB;       // K hi, K lo, Vt hi, Vt lo
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = p.seq_len[b];
+    if ((int)blockIdx.x * 64 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int fr = lane & 15, g = lane >> 4;
+    const long row0 = p.seq_off[b];
+    const float* base = reinterpret_cast<const float*>(p.qkv);
+    const float scale = 1.0f / sqrtf((float)DK);
+    constexpr float LO = 1.0f / 2048.0f;
+
+    h4 qh[NS], ql[NS];
+    {
+        const int qi = min(q0 + fr, len - 1);
+        const float4* qp = reinterpret_cast<const float4*>(base + (row0 + qi) * p.ld + h * DK + g * 12);
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const float4 t = qp[c];
+            const float x[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
+            split4(x, qh[c], ql[c]);
+        }
+    }
+    // staging roles: unit u = tid + 256 j, j = 0..2; u < 384: K unit (key u / 12, float4 u % 12), else V unit u - 384
+    int ukey[3], uc4[3];
+    bool uv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { int u = tid + 256 * j; uv[j] = u >= 384; if (uv[j]) u -= 384; ukey[j] = u / 12; uc4[j] = u % 12; }
+    float4 st[3];
+    const int nstage = (len + KT - 1) / KT;
+#define EV_ATL_LOAD(S)                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                      \
+        const int kr_ = min((S) * KT + ukey[j], len - 1);                                                                \
+        st[j] = *reinterpret_cast<const float4*>(base + (row0 + kr_) * p.ld + (uv[j] ? 2 : 1) * p.C + h * DK + uc4[j] * 4); \
+    }
+#define EV_ATL_STORE(BUF)                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                      \
+        const float x_[4] = {st[j].x, st[j].y, st[j].z, st[j].w};                                                        \
+        h4 hi_, lo_;                                                                                                     \
+        split4(x_, hi_, lo_);                                                                                            \
+        char* sb_ = lds + (BUF) * STAGE;                                                                                 \
+        if (!uv[j]) {                                                                                                    \
+            *reinterpret_cast<h4*>(sb_ + ukey[j] * KP + uc4[j] * 8) = hi_;                                               \
+            *reinterpret_cast<h4*>(sb_ + KB + ukey[j] * KP + uc4[j] * 8) = lo_;                                          \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+                *reinterpret_cast<_Float16*>(sb_ + 2 * KB + (uc4[j] * 4 + e) * VP + ukey[j] * 2) = hi_[e];               \
+                *reinterpret_cast<_Float16*>(sb_ + 2 * KB + VB + (uc4[j] * 4 + e) * VP + ukey[j] * 2) = lo_[e];          \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+    f4 oh[ND], ox[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) { oh[dt] = f4{0.f, 0.f, 0.f, 0.f}; ox[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
+    float m = -INFINITY, l = 0.f;
+    EV_ATL_LOAD(0)
+    EV_ATL_STORE(0)
+    __syncthreads();
+    for (int sg = 0; sg < nstage; ++sg) {
+        if (sg + 1 < nstage) EV_ATL_LOAD(sg + 1)
+        const char* sb = lds + (sg & 1) * STAGE;
+#pragma unroll
+        for (int half = 0; half < KT / 16; ++half) {
+            const int kbase = sg * KT + half * 16;
+            if (kbase >= len) break;                              // (uniform: the stage's second 16 keys may lie beyond the utterance)
+            f4 sh = f4{0.f, 0.f, 0.f, 0.f}, sx = f4{0.f, 0.f, 0.f, 0.f};
+            const char* kp = sb + (half * 16 + fr) * KP + g * 24;
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                const h4 kh = *reinterpret_cast<const h4*>(kp + c * 8), kl = *reinterpret_cast<const h4*>(kp + KB + c * 8);
+                sh = __builtin_amdgcn_mfma_f32_16x16x16f16(kh, qh[c], sh, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_16x16x16f16(kh, ql[c], sx, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_16x16x16f16(kl, qh[c], sx, 0, 0, 0);
+            }
+            float sc[4];
+            float cm = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i] = (kbase + 4 * g + i < len) ? sh[i] + sx[i] * LO : -INFINITY;
+                cm = fmaxf(cm, sc[i]);
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float mn = fmaxf(m, cm);
+            const float alpha = expf(m - mn);
+            m = mn;
+            float pr[4];
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pr[i] = expf(sc[i] - mn); ps += pr[i]; }
+            l = l * alpha + ps;
+            h4 ph, pl;
+            split4(pr, ph, pl);
+            const char* vp = sb + 2 * KB + fr * VP + (half * 16 + 4 * g) * 2;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const h4 vh = *reinterpret_cast<const h4*>(vp + dt * 16 * VP), vl = *reinterpret_cast<const h4*>(vp + VB + dt * 16 * VP);
+                oh[dt] *= alpha; ox[dt] *= alpha;
+                oh[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, ph, oh[dt], 0, 0, 0);
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, pl, ox[dt], 0, 0, 0);
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vl, ph, ox[dt], 0, 0, 0);
+            }
+        }
+        if (sg + 1 < nstage) EV_ATL_STORE((sg + 1) & 1)        // (the other buffer: its last readers finished before the previous barrier)
+        __syncthreads();
+    }
+#undef EV_ATL_LOAD
+#undef EV_ATL_STORE
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (q0 + fr < len) {
+        const float inv = 1.0f / l;
+        float* op = reinterpret_cast<float*>(p.out) + (row0 + q0 + fr) * p.ldo + h * DK + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const f4 o = oh[dt] + ox[dt] * LO;
+            *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        }
+    }
+}
+
 void launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.dtype == DT_F32S && p.C / p.heads == 48) {          // fp32 rows, split-precision products (decoder, strict / mx modes)
-        hipLaunchKernelGGL((attention_mfma_x3_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+        static const bool no_lds = getenv("EV_ATTN_X3_NOLDS") != nullptr;     // A/B switch: every wave fetches and splits its own tiles
+        if (no_lds) hipLaunchKernelGGL((attention_mfma_x3_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attention_mfma_x3_lds_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
         return;
     }
     if (p.dtype == DT_F16) {
