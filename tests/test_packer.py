@@ -61,7 +61,7 @@ def test_blob_table_and_manifest(packed):
     assert t["voc.up0.w16"].shape == (8 * 256, 3, 512) and t["voc.up3.w16"].shape == (2 * 32, 3, 64)
     assert t["voc.rb11.c2.2.w16"].shape == (32, 11, 32) and t["voc.post.w"].shape == (7, 32)
     for k, v in t.items():
-        if k.endswith(".wmx") or k.endswith(".wpmx"):
+        if k.endswith(("mx",)):            # .wmx / .wpmx / .wcmx
             continue                                   # opaque fp4 planes stored under an fp16-typed entry (test_mx_weight_planes)
         assert np.isfinite(v.astype(np.float32)).all(), k
 
@@ -145,8 +145,11 @@ def test_mx_weight_planes(packed):
     sd, tsd, t, man = packed
     mx = sorted(k for k in t if k.endswith(".wmx"))
     pmx = sorted(k for k in t if k.endswith(".wpmx"))
-    assert [k for k in mx if ".up" in k] == ["voc.up0.wmx", "voc.up1.wmx", "voc.up2.wmx"]
+    assert [k for k in mx if k.startswith("voc.up")] == ["voc.up0.wmx", "voc.up1.wmx", "voc.up2.wmx"]
+    assert sorted(k for k in mx if k.startswith("dec.")) == sorted("dec.%d.ffn%d.wmx" % (i, j) for i in range(4) for j in (1, 2))
     assert len([k for k in mx if ".rb" in k]) == 2 * 3 * 3 * 2 and all(int(k.split(".")[1][2:]) < 6 for k in mx if ".rb" in k)
+    cmx = sorted(k for k in t if k.endswith(".wcmx"))            # C = 64: stage 2 + the last up-conv
+    assert len(cmx) == 3 * 3 * 2 + 1 and "voc.up3.wcmx" in cmx and all(6 <= int(k.split(".")[1][2:]) < 9 for k in cmx if ".rb" in k)
     assert len(pmx) == 3 * 3 * 2 and all(int(k.split(".")[1][2:]) >= 9 for k in pmx)
     for name, shape in (("voc.rb0.c1.1", (256, 3, 256)), ("voc.rb5.c2.0", (128, 11, 128)), ("voc.up1", (1024, 3, 256))):
         w16 = t[name + ".w16"].astype(np.float32)
