@@ -44,8 +44,8 @@ PEAK_HBM = 8000.0                                  # GB/s
 DTYPE_NAME = {"f16": "f16", "x3": "f16x3 (fp16 hi/lo split, 3 MFMAs per product, fp32 activations)",
               "mx": "f16+mxfp4 (fp32 activations; per product one fp16 MFMA on the hi parts + two block-scaled fp4 MFMAs for the cross terms; "
                     "split-precision fp16x3 where channels < 128 and in the mel decoder)"}
-# measured DC-free relative L2 of the waveform against the reference's own outputs (tests/test_gpu_parity.py, profiles/r3_*_parity_report.json)
-PARITY_LEVEL = {"mx": "<= 3.2e-4 on every fixture incl. zero-mean (bar 1e-3)", "fast": "2.4e-3 on zero-mean audio (bar 1e-3: NOT met)",
+# measured DC-free relative L2 of the waveform against the reference's own outputs (tests/test_gpu_parity.py, profiles/r3_h_parity_report.json)
+PARITY_LEVEL = {"mx": "<= 4.4e-4 on every fixture incl. zero-mean and trained-like gains (bar 1e-3)", "fast": "2.4e-3 on zero-mean audio (bar 1e-3: NOT met)",
                 "strict": "<= 3e-6"}
 REFERENCE_CPU_FRAMES_PER_S = 628.0                 # the reference's own JETSGenerator, 8 Xeon cores, B = 1, N = 256
 

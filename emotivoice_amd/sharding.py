@@ -10,8 +10,9 @@ from __future__ import annotations
 from typing import List, Sequence
 
 
-def broadcast_blob(rank: int, world: int, local_rank: int, dist, dur_mode: str = "bench", state_dict=None, device=None):
-    """Return a uint8 tensor holding the packed weight blob on this rank's device (CPU if device='cpu')."""
+def broadcast_blob(rank: int, world: int, local_rank: int, dist, dur_mode: str = "bench", state_dict=None, device=None, collective=None):
+    """Return a uint8 tensor holding the packed weight blob on this rank's device (CPU if device='cpu').  ``collective``: run the two
+    broadcasts (size, bytes) even in a world of one -- how the single-GPU test box exercises the RCCL branch; default: world > 1."""
     import numpy as np
     import torch
 
@@ -26,7 +27,7 @@ def broadcast_blob(rank: int, world: int, local_rank: int, dist, dur_mode: str =
         n = torch.tensor([t.numel()], dtype=torch.int64)
     else:
         t, n = None, torch.zeros(1, dtype=torch.int64)
-    if world > 1:
+    if world > 1 if collective is None else collective:
         n = n.to(dev)
         dist.broadcast(n, 0)
         if rank != 0:
