@@ -700,7 +700,8 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_lds_kernel(const AttnPa
     const int fr = lane & 15, g = lane >> 4;
     const long row0 = p.seq_off[b];
     const float* base = reinterpret_cast<const float*>(p.qkv);
-    const float scale = 1.0f / sqrtf((float)DK);
+    // scores are kept in log2 units (log2 e folded into the query scale): the softmax is two v_exp_f32 chains shorter per element than with expf
+    const float scale = 1.4426950408889634f / sqrtf((float)DK);
     constexpr float LO = 1.0f / 2048.0f;
 
     h4 qh[NS], ql[NS];
@@ -775,12 +776,12 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_lds_kernel(const AttnPa
             cm = fmaxf(cm, __shfl_xor(cm, 16));
             cm = fmaxf(cm, __shfl_xor(cm, 32));
             const float mn = fmaxf(m, cm);
-            const float alpha = expf(m - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);            // (m = -inf on the first tile -> 0)
             m = mn;
             float pr[4];
             float ps = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { pr[i] = expf(sc[i] - mn); ps += pr[i]; }
+            for (int i = 0; i < 4; ++i) { pr[i] = __builtin_amdgcn_exp2f(sc[i] - mn); ps += pr[i]; }
             l = l * alpha + ps;
             h4 ph, pl;
             split4(pr, ph, pl);
