@@ -149,9 +149,15 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
     EV_C64_SSTORE()
     __syncthreads();
     const int wrow0 = wave * 32 + fr;
+    // EV_C64_TIMING (tuning builds: build.py --variant c64t EV_C64_TIMING): wave 0 of block 0 sums the cycles of each section of an item and writes
+    // them over out32[0..6] at the end (tools/bench_c64.py); every s_memtime is a scalar-memory round trip, so the product build has none
+#ifdef EV_C64_TIMING
     unsigned long long tk_prev = __builtin_readcyclecounter();
     unsigned tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define EV_C64_TICK(I) { const unsigned long long t_ = __builtin_readcyclecounter(); tk[I] += (unsigned)(t_ - tk_prev); tk_prev = t_; }
+#else
+#define EV_C64_TICK(I)
+#endif
     for (; item < nitems; item += gridDim.x) {
         const int tile = EV_C64_TILE(item);
         const bool item_ok = EV_C64_OK(item);
@@ -303,12 +309,16 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
         EV_C64_TICK(4)
         __syncthreads();          // the new slab is complete
         EV_C64_TICK(5)
+#ifdef EV_C64_TIMING
         tk[6] += 1;
+#endif
     }
+#ifdef EV_C64_TIMING
     if ((abl & 64) && blockIdx.x == 0 && tid == 0) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) reinterpret_cast<unsigned*>(p.out32)[i] = tk[i];
     }
+#endif
 #undef EV_C64_TICK
 #undef EV_C64_GLOAD
 #undef EV_C64_SSTORE

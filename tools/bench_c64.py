@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Tuning probe for conv_c64_mx_kernel (ev_conv64_mx.h) at the stage-2 size of BASELINE configs[1]: times conv1 / conv2 forms for k = 3 / 7 / 11 with
-one ingredient dropped at a time (ev_conv_gemm_desc.reserved0 bits 4-9).    python tools/bench_c64.py [--rows 4227072]"""
+one ingredient dropped at a time (ev_conv_gemm_desc.reserved0 bits 4-9).    python tools/bench_c64.py [--rows 4227072]
+Per-section cycle sums need the timing build:  python emotivoice_amd/csrc/build.py --variant c64t EV_C64_TIMING;  EVHIP_LIB=emotivoice_amd/csrc/libevhip_c64t.so python tools/bench_c64.py"""
 import argparse
 import ctypes as C
 import os
@@ -63,7 +64,7 @@ def main():
                 e1.record(st)
                 torch.cuda.synchronize()
                 print("k=%2d %-5s %-24s %8.1f us" % (k, form, nm, e0.elapsed_time(e1) / 5 * 1e3), flush=True)
-            if form == "conv2":          # where a wave's cycles go (reserved0 bit 10: wave 0 of block 0 writes its section sums over out32[0..6])
+            if form == "conv2" and os.environ.get("EVHIP_LIB"):          # tuning build with -DEV_C64_TIMING (EVHIP_LIB=.../libevhip_c64t.so): where a wave's cycles go
                 d.reserved0 = 64 << 4
                 lib.ev_op_conv_gemm(C.byref(d), None)
                 torch.cuda.synchronize()
