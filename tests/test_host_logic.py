@@ -121,3 +121,24 @@ def test_generator_protocol_errors_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(EVError):
             g.to("cuda:0")
+
+
+def test_g2p_standin_is_deterministic_and_pool_consistent():
+    """The front-end stand-in used by tools/bench_frontend.py and bench.py --mode pipeline (the reference's English lexicon-path work on a
+    seeded synthetic lexicon): deterministic, every output token is in its token table, and FrontendPool returns exactly the serial result."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from g2p_standin import make_g2p, make_lexicon, make_text, token_table
+    from emotivoice_amd.frontend_pool import FrontendPool
+    lex = make_lexicon(5000, seed=3)
+    assert lex == make_lexicon(5000, seed=3) and len(lex) > 4000
+    g2p = make_g2p(lex)
+    texts = make_text(lex, 200, words_per_line=9, seed=4, oov_rate=0.05)
+    out = [g2p(t) for t in texts]
+    tab = token_table()
+    assert all(tok in tab for line in out for tok in line.split())
+    assert all(line.startswith("<sos/eos> ") and line.endswith(" <sos/eos>") and "engsp" not in line.split()[-2] for line in out)
+    assert any("engsp4" in line for line in out) and any("engsp1" in line for line in out)
+    with FrontendPool(g2p, workers=2, chunk=16) as pool:
+        assert pool.map(texts) == out
