@@ -37,6 +37,9 @@ VOC_CONV_FLOP_PER_FRAME = 614.105e6 - 0.115e6      # every Conv1d/ConvTranspose1
 VOC_STAGE3_RB_FLOP_PER_FRAME = (9.437 + 22.020 + 34.603) * 1e6   # stage-3 ResBlocks (C = 32): run by the fused pair kernel (fast mode)
 VOC_STAGE2_K3_RB_FLOP_PER_FRAME = 18.874e6         # stage-2 k = 3 ResBlock (C = 64): run by the C = 64 fused pair kernel (fast mode)
 VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
+# the mx mode's own layer-wise contract: plane sets of 3.0625 B per element between the >= 64-channel layers (conv1 of a pair:
+# planes in / planes out; conv2: planes + fp32 residual in, fp32 + planes out), fp32 running MRF sums, the fused C = 32 pairs at 8 B per element
+VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": 4.310e6}
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_MFMA_FP4 = 10000.0                            # TFLOP/s dense, block-scaled fp4 / fp6 (MI355X_MICROARCH.md)
@@ -209,12 +212,14 @@ def roofline_block(eng, work, torch, strict=None):
                               issued_equiv_frac=round(u * tf / PEAK_MFMA_F16, 4))
             voc_ms += st["ms"]
             voc_issued += u * st["flops"]
+        voc_pmc = None               # PMC-measured HBM bytes of the whole generator per mel frame, this mode
         traffic = tnote = None      # HBM bytes per launch of the dominant family from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
         tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
         if os.path.exists(tpath) and work.mode == "am_vocoder" and B == 32:
             t = json.load(open(tpath))
             t = t.get(mode, t if mode == "f16" and "hbm_bytes_per_launch" in t else {})          # one entry per precision mode (tools/profile_summary.py)
             traffic = t.get("hbm_bytes_per_launch")
+            voc_pmc = t.get("vocoder_hbm_bytes_per_frame")
             tnote = "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json"
         # dense MFMA peak of the family's ARITHMETIC per algorithmic product: fp16 2.5 PF/s; split precision = three fp16 MFMAs -> 2.5 / 3;
         # mx = one fp16 MFMA (2.5 PF/s) + two fp4 MFMAs (10 PF/s, MI355X_MICROARCH.md) -> 1 / (1 / 2.5 + 2 / 10) = 1.667 PF/s
@@ -230,9 +235,15 @@ def roofline_block(eng, work, torch, strict=None):
                     families=fams,
                     all_vocoder_convs=dict(ms=round(voc_ms, 3), mfma_TFLOPs=round(VOC_CONV_FLOP_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e12, 2),
                                            issued_equiv_frac=round(voc_issued / (voc_ms * 1e-3) / 1e12 / PEAK_MFMA_F16, 4),
-                                           hbm_contract_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9, 1),
-                                           hbm_contract_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
-                                           hbm_contract_note="the layer-wise fp16 contract (2.026 MB / frame); fp32-class modes move 2x that layer-wise"))
+                                           hbm_contract_GBps=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9, 1),
+                                           hbm_contract_frac=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
+                                           hbm_contract_bytes_per_frame=VOC_BYTES_PER_FRAME_BY_MODE[mode],
+                                           hbm_contract_note="this mode's layer-wise byte contract (fp16: 2.026 MB / frame; split precision: fp32 tensors, 2x; "
+                                                             "mx: plane sets + fp32 residual streams, 4.31 MB / frame)"))
+        if voc_pmc:
+            roof["all_vocoder_convs"].update(hbm_pmc_bytes_per_frame=round(voc_pmc, 1), hbm_pmc_GBps=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9, 1),
+                                             hbm_pmc_frac=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
+                                             hbm_pmc_note="bytes the generator actually moves (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, calibrated) / time")
     if roof is not None and "decoder" in stages and stages["decoder"] > 0:
         dflop = decoder_flops(f1 / max(B, 1)) * B if work.mode == "am_vocoder" else None
         if dflop:
