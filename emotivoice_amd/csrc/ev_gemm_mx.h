@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
     const int m0 = (bid / nN) * BM, nt = bid % nN, n0 = nt * 128;
-    const int nkc16 = p.K >> 5, nkc4 = p.K >> 7;
+    const int nkc16_ = p.K >> 5, nkc4 = p.K >> 7;
     const unsigned K2 = (unsigned)p.K >> 1;                // row / tap pitch of a fp4 plane in bytes; the fp16 planes' is 4 x that
     const unsigned wrp4 = K2 * TAPS;
     const int row0 = m0 - p.center * p.dil;                // first slab row (negative for the first tile: slack rows)
@@ -253,6 +253,14 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     // two loops, not one loop with an fp16 / fp4 branch: with both bodies behind a branch hipcc gave the accumulators different registers on the
     // two paths (64 moves per chunk and 80-150 spilled registers); back to back they simply flow from the first loop into the second
     int sbase = 0, q = 0;
+    // EV_MX_ABL (tuning builds: build.py --variant mxabl EV_MX_ABL; tools/bench_mxgemm.py): reserved0 bit 4 = one chunk per pass instead of K / 32 and
+    // K / 128 (prologue + epilogue of a tile with a minimal main loop), bit 5 = no epilogue (results are garbage by design)
+#ifdef EV_MX_ABL
+    const int abl = p.reserved0 >> 4;
+    const int nkc16 = (abl & 1) ? 1 : nkc16_, n4half = (abl & 1) ? 1 : nkc4;
+#else
+    const int nkc16 = nkc16_, n4half = nkc4;
+#endif
     for (int kc = 0; kc < nkc16; ++kc, ++q) {            // fp16 pass; a next chunk always exists (K % 128 == 0: nkc4 >= 1)
         const bool more = true, lastc = kc + 1 == nkc16;
         const char* const cwb = wb16 + (unsigned)kc * 64u;
@@ -268,12 +276,12 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
         for (int u = 0; u < U; ++u) EV_MX_STEP(false, 2, u)
         sbase += U;
     }
-    const int n4 = 2 * nkc4;
+    const int n4 = 2 * n4half;
     for (int q4 = 0; q4 < n4; ++q4, ++q) {               // Q(wl).Q(xh) over the K chunks, then Q(wh).Q(xl)
         const bool more = q4 + 1 < n4;
         const int qn = more ? q4 + 1 : q4;
-        const bool sec = q4 >= nkc4, secn = qn >= nkc4;
-        const unsigned kc = (unsigned)(sec ? q4 - nkc4 : q4), kn = (unsigned)(secn ? qn - nkc4 : qn);
+        const bool sec = q4 >= n4half, secn = qn >= n4half;
+        const unsigned kc = (unsigned)(sec ? q4 - n4half : q4), kn = (unsigned)(secn ? qn - n4half : qn);
         const char* const cwb = uniform_ptr(wb4l + (sec ? dw4 : 0L) + kc * 64u);
         const char* const nxb = uniform_ptr(xb4h + (secn ? dx4 : 0L) + kn * 64u);
         const char* const nwb = uniform_ptr(wb4l + (secn ? dw4 : 0L) + kn * 64u);
@@ -293,6 +301,19 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wc == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+#ifdef EV_MX_ABL
+    if (abl & 2) {
+        if (p.M < 0) {          // never: keeps the accumulators alive
+            float sum = 0.f;
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+            p.out32[tid] = sum;
+        }
+        return;
+    }
+#endif
     if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC);
     else {
         EV_TRACE_EPI_DUMMY

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Tuning probe for conv_gemm_mx_kernel (ev_gemm_mx.h) at the stage-0 / stage-1 sizes of BASELINE configs[1]: times the conv1 form (plane set in,
+leaky-relu, plane set out) and the conv2 form (plane set + fp32 residual in, fp32 + plane set out) for k = 3 / 7 / 11.
+
+    python tools/bench_mxgemm.py [--c 128] [--rows 2113536] [--ks 3,7,11]
+
+With the ablation build (python emotivoice_amd/csrc/build.py --variant mxabl EV_MX_ABL;  EVHIP_LIB=emotivoice_amd/csrc/libevhip_mxabl.so) each form is
+also timed with a one-chunk main loop (what a tile costs outside its K loop) and without its epilogue (ev_conv_gemm_desc.reserved0 bits 4 / 5)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emotivoice_amd import _ffi, mxfp4  # noqa: E402
+
+PAD = 64
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c", type=int, default=128)
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--ks", default="3,7,11")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    lib = _ffi.lib()
+    Cc = args.c
+    M = (args.rows or (270532608 // Cc)) // 256 * 256          # rows x channels of a ResBlock tensor of configs[1] (33024 frame rows x 8192 / C)
+    R = M + 2 * PAD
+    nch = Cc // 128
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def plane_set():
+        h = torch.randn(R, Cc, device="cuda", generator=g).half()
+        q = [torch.randint(0, 255, (R, Cc // 2), device="cuda", dtype=torch.uint8, generator=g) for _ in range(2)]
+        s = [torch.full((nch, R, 4), 120, device="cuda", dtype=torch.uint8) for _ in range(2)]
+        return h, q, s
+
+    xi, xo = plane_set(), plane_set()
+    res = torch.randn(M, Cc, device="cuda", generator=g)
+    out = torch.empty(M, Cc, device="cuda")
+    bias = torch.zeros(Cc, device="cuda")
+    abl_build = "mxabl" in os.environ.get("EVHIP_LIB", "")
+    names = {0: "full"}
+    if abl_build:
+        names.update({1: "one-chunk main loop", 2: "no epilogue", 3: "one chunk, no epilogue"})
+    for k in [int(x) for x in args.ks.split(",")]:
+        wg = (np.random.default_rng(k).standard_normal((Cc, k, Cc)) / np.sqrt(Cc * k)).astype(np.float32)
+        d_hi = torch.from_numpy(wg.astype(np.float16)).cuda()
+        d_mx = torch.from_numpy(mxfp4.pack_weight_planes(wg)).cuda()
+        for form in ("conv1", "conv2"):
+            for abl, nm in list(names.items()) + [(0, "full (again)")]:          # (the first timing of a weight set runs 5-15 % slow: clocks)
+                d = _ffi.ev_conv_gemm_desc()
+                h, q, s = xi
+                d.dtype, d.A, d.lda, d.W, d.W_lo, d.W_mx = 3, h[PAD:].data_ptr(), Cc, d_hi.data_ptr(), d_hi.data_ptr(), d_mx.data_ptr()
+                d.mx_x4[0], d.mx_x4[1] = q[0][PAD:].data_ptr(), q[1][PAD:].data_ptr()
+                d.mx_xs[0], d.mx_xs[1], d.mx_xs_stride = s[0][0, PAD:].data_ptr(), s[1][0, PAD:].data_ptr(), R * 4
+                d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale, d.ldo = bias.data_ptr(), M, Cc, Cc, k, 1, (k - 1) // 2, 1.0, Cc
+                oh, oq, osc = xo
+                d.mxo_h, d.mxo_logC, d.mxo_slope, d.mxo_qs_stride = oh[PAD:].data_ptr(), 0, 0.1, R * 4
+                d.mxo_q4[0], d.mxo_q4[1] = oq[0][PAD:].data_ptr(), oq[1][PAD:].data_ptr()
+                d.mxo_qs[0], d.mxo_qs[1] = osc[0][0, PAD:].data_ptr(), osc[1][0, PAD:].data_ptr()
+                if form == "conv1":
+                    d.act, d.act_slope = 3, 0.1
+                else:
+                    d.res, d.res_dtype, d.ldres, d.out32 = res.data_ptr(), 1, Cc, out.data_ptr()
+                d.reserved0 = abl << 4
+                for _ in range(6):
+                    rc = lib.ev_op_conv_gemm(C.byref(d), None)
+                    assert rc == 0, rc
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st = torch.cuda.current_stream()
+                e0.record(st)
+                for _ in range(args.reps):
+                    lib.ev_op_conv_gemm(C.byref(d), C.c_void_p(st.cuda_stream))
+                e1.record(st)
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / args.reps * 1e3
+                fl = 2.0 * M * Cc * Cc * k
+                by = M * Cc * (3.0625 * 2 + (8 if form == "conv2" else 0))
+                print("C=%d M=%d k=%2d %-5s %-24s %8.1f us  %6.0f TF/s alg  %5.2f TB/s contract" % (Cc, M, k, form, nm, us, fl / us / 1e6, by / us / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
