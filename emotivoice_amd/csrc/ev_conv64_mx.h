@@ -93,6 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
     // requests after the first, 7 no MFMAs, 8 no LDS slab writes after the first, 9 no plane quantisation at all
     const int abl = p.reserved0 >> 4;
     const f32x2 mxo_slope2 = f32x2{p.mxo_slope, p.mxo_slope};
+    const bool mxo_act = p.mxo_slope != 1.0f, scaled = p.out_scale != 1.0f;          // (x * 1 is exact)
     float* const o32 = p.out32;
     const uint8_t* vptr = p.row_valid ? p.row_valid : g_row_always_valid;
     const int vshift = p.row_valid ? p.valid_shift : 31;
@@ -271,18 +272,28 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
                 const f32x2 rr[4] = {f32x2{resv[it][0].x, resv[it][0].y}, f32x2{resv[it][0].z, resv[it][0].w},
                                      f32x2{resv[it][1].x, resv[it][1].y}, f32x2{resv[it][1].z, resv[it][1].w}};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (v[q] + rr[q]) * out_scale2;
+                for (int q = 0; q < 4; ++q) v[q] += rr[q];
+                if (scaled) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= out_scale2;
+                }
             }
             if constexpr (MODE == 2) {
                 v[0] += f32x2{accin[it][0].x, accin[it][0].y}; v[1] += f32x2{accin[it][0].z, accin[it][0].w};
                 v[2] += f32x2{accin[it][1].x, accin[it][1].y}; v[3] += f32x2{accin[it][1].z, accin[it][1].w};
             }
+            if (vmask != 0xffffffffu) {            // (wave-uniform: a 32-row group with rows outside the utterances)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q][0] = valid ? v[q][0] : 0.f; v[q][1] = valid ? v[q][1] : 0.f; }
+                for (int q = 0; q < 4; ++q) { v[q][0] = valid ? v[q][0] : 0.f; v[q][1] = valid ? v[q][1] : 0.f; }
+            }
             if (has_planes && !(abl & 32)) {            // the next conv's operand: its leaky-relu, then the planes (this quad = one 32-channel block of the row)
                 f32x2 am[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) am[q] = lrelu2(v[q], mxo_slope2);
+                for (int q = 0; q < 4; ++q) am[q] = v[q];
+                if (mxo_act) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) am[q] = lrelu2(v[q], mxo_slope2);
+                }
                 mx_quant8(am, pho[it], pch[it], pcl[it], pbh[it], pbl[it]);
             }
         }

@@ -54,6 +54,12 @@ __device__ __forceinline__ float max_raw(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// max(|a|, |b|, m) in one VALU (source modifiers), m >= 0: the block maxima of mx_quant8 took an and + a max per element before
+__device__ __forceinline__ float max3_abs_raw(float a, float b, float m) {
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
 __device__ __forceinline__ unsigned pk_max_f16_raw(unsigned a, unsigned b) {
     unsigned r;
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -283,8 +289,8 @@ __device__ __forceinline__ void mx_quant8(const f32x2 (&a)[4], uint4& ho, unsign
         hh[j] = __builtin_convertvector(a[j], half2v);
         hf[j] = __builtin_convertvector(hh[j], f32x2);
         lf[j] = a[j] - hf[j];
-        mh = max_raw(mh, max_raw(__builtin_fabsf(hf[j][0]), __builtin_fabsf(hf[j][1])));
-        ml = max_raw(ml, max_raw(__builtin_fabsf(lf[j][0]), __builtin_fabsf(lf[j][1])));
+        mh = max3_abs_raw(hf[j][0], hf[j][1], mh);
+        ml = max3_abs_raw(lf[j][0], lf[j][1], ml);
     }
     // (DPP quad permutes: __shfl_xor compiles to ds_bpermute_b32 -- an LDS-pipe round trip with its own address arithmetic, four of them in
     // a dependent chain per call, which measured a third of conv_c64_mx_kernel's k = 3 launches)
@@ -304,7 +310,14 @@ __device__ __forceinline__ void mx_quant8(const f32x2 (&a)[4], uint4& ho, unsign
 // code plane and (first lane of the block) one byte of each scale plane.
 // (row, co) = the element's position in the launch's own [M][N] output; mxo_logC == 0: that IS the plane set's geometry (C = N, any multiple
 // of 128), else the planes are [M * N / C][C] with C = 2^mxo_logC (a transposed conv's polyphase output).
-__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, long row_, int co, int lane) {
+// byte offset of the scale of element (row, co) of the launch's [M][N] output inside a scale plane
+__device__ __forceinline__ long mx_scale_offset(const ConvGemmParams& p, long lin, long row_, int co) {
+    const long row = p.mxo_logC ? (lin >> p.mxo_logC) : row_;
+    const unsigned c = p.mxo_logC ? ((unsigned)lin & ((1u << p.mxo_logC) - 1u)) : (unsigned)co;
+    return (long)(c >> 7) * p.mxo_qs_stride + row * 4 + ((c >> 5) & 3);
+}
+// (so = mx_scale_offset of the element: the caller advances it by 4 bytes per plane-set row instead of recomputing it -- ~12 VALU per call)
+__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, long so, int lane) {
     uint4 ho;
     unsigned ch, cl, bh, bl;
     mx_quant8(a, ho, ch, cl, bh, bl);
@@ -312,9 +325,6 @@ __device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f3
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;
     if ((lane & 3) == 0) {
-        const long row = p.mxo_logC ? (lin >> p.mxo_logC) : row_;
-        const unsigned c = p.mxo_logC ? ((unsigned)lin & ((1u << p.mxo_logC) - 1u)) : (unsigned)co;
-        const long so = (long)(c >> 7) * p.mxo_qs_stride + row * 4 + ((c >> 5) & 3);
         reinterpret_cast<uint8_t*>(p.mxo_qs[0])[so] = (uint8_t)bh;
         reinterpret_cast<uint8_t*>(p.mxo_qs[1])[so] = (uint8_t)bl;
     }
@@ -384,6 +394,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     const bool has_post = p.post_lrelu != 0;
     const f32x2 post_slope2 = f32x2{p.post_slope, p.post_slope};
     const f32x2 mxo_slope2 = f32x2{p.mxo_slope, p.mxo_slope};
+    const bool mxo_act = p.mxo_slope != 1.0f, scaled = p.out_scale != 1.0f;          // (x * 1 is exact: skipping it changes no bit)
     __half* const o16 = reinterpret_cast<__half*>(p.out16);
     float* const o32a = p.out32_before_post ? p.out32 : nullptr;
     float* const o32b = p.out32_before_post ? nullptr : p.out32;
@@ -391,6 +402,14 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     unsigned lrbit[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) lrbit[it] = 1u << (it * RPI + rr);
+    // plane-set output: the lane's scale byte moves by a fixed distance per output row (ldo == N is a multiple of the plane set's C, so a
+    // step of one [M][N] row is N / C whole plane-set rows and the channel block stays the lane's own)
+    long mx_so0 = 0;
+    int mx_sstep = 0;
+    if constexpr (EPI & EPI_MXP) {
+        mx_so0 = mx_scale_offset(p, rowoff, (long)trow, co);
+        mx_sstep = 4 * (p.mxo_logC ? (p.ldo >> p.mxo_logC) : 1);
+    }
     EV_STAMP()
 
 #pragma unroll
@@ -445,8 +464,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 const float4 r0 = r32[EV_EPI_SET(pass)][it][0], r1 = r32[EV_EPI_SET(pass)][it][1];
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
             }
+            if (scaled) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= out_scale2;
+                for (int j = 0; j < 4; ++j) v[j] *= out_scale2;
+            }
             if constexpr (EPI & EPI_ACC32) {
                 const float4 r0 = a32[EV_EPI_SET(pass)][it][0], r1 = a32[EV_EPI_SET(pass)][it][1];
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
@@ -457,36 +478,45 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += __builtin_convertvector(ha[j], f32x2) + __builtin_convertvector(hb[j], f32x2);
             }
-            const bool valid = (vmask[pass] & lrbit[it]) != 0u;
-            constexpr bool STATIC_OUT = (EPI & (EPI_O16 | EPI_O32)) != 0;
+            // rows outside the utterances give zeros in every output (leaky-relu and the conversions keep +0): masked once, and only in a
+            // 32-row group that has such rows at all (wave-uniform; VALU only, so no store count depends on it)
+            if (vmask[pass] != 0xffffffffu) {
+                const bool valid = (vmask[pass] & lrbit[it]) != 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j][0] = valid ? v[j][0] : 0.f; v[j][1] = valid ? v[j][1] : 0.f; }
+            }
+            // (an EPI_MXP launch has no run-time outputs either: mx_epi_variant admits plane sets only beside / instead of ONE fp32 output)
+            constexpr bool STATIC_OUT = (EPI & (EPI_O16 | EPI_O32 | EPI_MXP)) != 0;
             if (!STATIC_OUT && o32a) {
                 float* op = o32a + off;
-                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(op) = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
             }
-            if (has_post) {
+            if (!(EPI & EPI_MXP) && has_post) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = lrelu2(v[j], post_slope2);
             }
             if ((EPI & EPI_O32) || (!STATIC_OUT && o32b)) {
                 float* op = o32b + off;
-                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(op) = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
             }
             if ((EPI & EPI_O16) || (!STATIC_OUT && o16)) {
                 uint4 o;
                 half2v* h = reinterpret_cast<half2v*>(&o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h[j] = __builtin_convertvector(v[j], half2v);
-                // zero rows outside the utterances: on the packed words (4 selects instead of 8)
-                o.x = valid ? o.x : 0u; o.y = valid ? o.y : 0u; o.z = valid ? o.z : 0u; o.w = valid ? o.w : 0u;
                 *reinterpret_cast<uint4*>(o16 + off) = o;
             }
             if constexpr (EPI & EPI_MXP) {            // the consumer's leaky-relu, then its operand planes (ldo == N: `off` is the linear offset)
                 f32x2 am[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { am[j] = lrelu2(v[j], mxo_slope2); am[j][0] = valid ? am[j][0] : 0.f; am[j][1] = valid ? am[j][1] : 0.f; }
-                mx_emit_planes(p, am, off, (long)trow + pass * 32 + it * RPI, co, lane);
+                for (int j = 0; j < 4; ++j) am[j] = v[j];
+                if (mxo_act) {            // (slope 1 = none: conv1 of a ResBlock pair, whose own leaky-relu is `act`)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) am[j] = lrelu2(v[j], mxo_slope2);
+                }
+                mx_emit_planes(p, am, off, mx_so0 + (long)((pass * 32 + it * RPI) * mx_sstep), lane);
             }
             EV_STAMP()
         }
