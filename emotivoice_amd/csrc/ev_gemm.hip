@@ -321,6 +321,18 @@ __device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f3
     uint4 ho;
     unsigned ch, cl, bh, bl;
     mx_quant8(a, ho, ch, cl, bh, bl);
+#ifdef EV_MX_ABL            // tuning build (tools/bench_mxgemm.py): reserved0 bit 6 = no plane stores at all, bit 7 = fp16 hi plane only, bit 8 = no scale bytes
+    const int abl = p.reserved0 >> 4;
+    if (abl & 4) { if (p.M < 0) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = uint4{ho.x ^ ch, ho.y ^ cl, ho.z ^ bh, ho.w ^ bl}; return; }
+    if (abl & 8) { if (p.M < 0) ho.x ^= ch ^ cl ^ bh ^ bl; *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho; return; }
+    if (abl & 16) {
+        if (p.M < 0) ho.x ^= bh ^ bl;
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho;
+        *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
+        *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;
+        return;
+    }
+#endif
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho;
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;

@@ -47,7 +47,7 @@ def main():
     abl_build = "mxabl" in os.environ.get("EVHIP_LIB", "")
     names = {0: "full"}
     if abl_build:
-        names.update({1: "one-chunk main loop", 2: "no epilogue", 3: "one chunk, no epilogue"})
+        names.update({1: "one-chunk main loop", 2: "no epilogue", 3: "one chunk, no epilogue", 4: "no plane stores", 8: "hi plane stored only", 16: "no scale bytes"})
     for k in [int(x) for x in args.ks.split(",")]:
         wg = (np.random.default_rng(k).standard_normal((Cc, k, Cc)) / np.sqrt(Cc * k)).astype(np.float32)
         d_hi = torch.from_numpy(wg.astype(np.float16)).cuda()
