@@ -60,6 +60,19 @@ __device__ __forceinline__ float max3_abs_raw(float a, float b, float m) {
     asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
     return r;
 }
+// max over lanes l, l ^ 16, l ^ 32, l ^ 48 without the LDS pipe (__shfl_xor is ds_bpermute_b32): v_permlane32_swap / v_permlane16_swap exchange
+// the upper half (odd 16-lane rows) of one register with the lower half (even rows) of another; applied to two copies of v they leave
+// {lo, lo} and {hi, hi}, whose maximum is the xor-32 (xor-16) reduction on every lane.  (inline asm: hipcc's builtin folded the second result away)
+__device__ __forceinline__ float max_xor32_raw(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return max_raw(a, b);
+}
+__device__ __forceinline__ float max_xor16_raw(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return max_raw(a, b);
+}
 __device__ __forceinline__ unsigned pk_max_f16_raw(unsigned a, unsigned b) {
     unsigned r;
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

@@ -8,6 +8,17 @@
 
 namespace ev {
 
+// maximum over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four 16-lane rows of a wave) without the LDS pipe: v_permlane32_swap / v_permlane16_swap
+// on two copies of the value leave {lower half, lower half} and {upper half, upper half}; their maximum is the xor reduction on every lane.
+// (__shfl_xor is ds_bpermute_b32: two dependent LDS round trips per key tile of the attention kernels.  Inline asm: hipcc's builtin folded the
+// second result away.)
+__device__ __forceinline__ float rows_max(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b); b = a;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -405,8 +416,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
                         mx = fmaxf(mx, v);
                     }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = rows_max(mx);
             const float mn = fmaxf(m[nq], mx);
             const float alpha = __builtin_amdgcn_exp2f(m[nq] - mn);
             m[nq] = mn;
@@ -538,8 +548,7 @@ __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParam
             sc[i] = (kt * 16 + 4 * g + i < len) ? st[i] : -INFINITY;
             cm = fmaxf(cm, sc[i]);
         }
-        cm = fmaxf(cm, __shfl_xor(cm, 16));
-        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        cm = rows_max(cm);
         const float mn = fmaxf(m, cm);
         const float alpha = expf(m - mn);            // m = -inf on the first tile -> 0
         m = mn;
@@ -647,8 +656,7 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_kernel(const AttnParams
             sc[i] = (kt * 16 + 4 * g + i < len) ? sh[i] + sx[i] * LO : -INFINITY;
             cm = fmaxf(cm, sc[i]);
         }
-        cm = fmaxf(cm, __shfl_xor(cm, 16));
-        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        cm = rows_max(cm);
         const float mn = fmaxf(m, cm);
         const float alpha = expf(m - mn);            // m = -inf on the first tile -> 0
         m = mn;
@@ -773,8 +781,7 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_lds_kernel(const AttnPa
                 sc[i] = (kbase + 4 * g + i < len) ? sh[i] + sx[i] * LO : -INFINITY;
                 cm = fmaxf(cm, sc[i]);
             }
-            cm = fmaxf(cm, __shfl_xor(cm, 16));
-            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            cm = rows_max(cm);
             const float mn = fmaxf(m, cm);
             const float alpha = __builtin_amdgcn_exp2f(m - mn);            // (m = -inf on the first tile -> 0)
             m = mn;

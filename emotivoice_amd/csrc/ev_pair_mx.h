@@ -223,13 +223,13 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx_kernel(const ResP
                     hh[a][q] = __builtin_convertvector(v[a][q], half2v);
                     hf[a][q] = __builtin_convertvector(hh[a][q], f32x2);
                     lf[a][q] = v[a][q] - hf[a][q];
-                    mh = max_raw(mh, max_raw(__builtin_fabsf(hf[a][q][0]), __builtin_fabsf(hf[a][q][1])));
-                    ml = max_raw(ml, max_raw(__builtin_fabsf(lf[a][q][0]), __builtin_fabsf(lf[a][q][1])));
+                    mh = max3_abs_raw(hf[a][q][0], hf[a][q][1], mh);
+                    ml = max3_abs_raw(lf[a][q][0], lf[a][q][1], ml);
                 }
             }
             // a row's 32 channels sit in the four k-groups of lanes (fr fixed): maxima across lanes l, l ^ 16, l ^ 32, l ^ 48
-            mh = max_raw(mh, __shfl_xor(mh, 16)); mh = max_raw(mh, __shfl_xor(mh, 32));
-            ml = max_raw(ml, __shfl_xor(ml, 16)); ml = max_raw(ml, __shfl_xor(ml, 32));
+            mh = max_xor16_raw(max_xor32_raw(mh));
+            ml = max_xor16_raw(max_xor32_raw(ml));
             const unsigned bh = mx_scale_byte(mh), bl = mx_scale_byte(ml);
             const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
 #pragma unroll
