@@ -104,6 +104,22 @@ def test_shard_utterances_balances_and_partitions():
     assert shard_utterances(lens, 8) == shards             # deterministic
 
 
+def test_generator_default_precision_is_the_contract_mode():
+    """The one-line swap of INTEGRATION.md (no precision argument) must land in the mode that meets the 1e-3 waveform contract; an explicit
+    component precision keeps the low-level resolution rule."""
+    from emotivoice_amd.engine import resolve_precision
+    from emotivoice_amd.generator import JETSGeneratorHIP
+    g = JETSGeneratorHIP(None)
+    assert resolve_precision(g._precision, g._dec_prec, g._voc_prec) == ("mx", "mx")
+    g = JETSGeneratorHIP(None, precision="fast")
+    assert resolve_precision(g._precision, g._dec_prec, g._voc_prec) == ("f16", "f16")
+    g = JETSGeneratorHIP(None, vocoder_precision="x3")
+    assert resolve_precision(g._precision, g._dec_prec, g._voc_prec) == ("f16", "x3")
+    assert resolve_precision(None, None, None) == ("f16", "f16")          # EVEngine itself keeps the fp16 default
+    with pytest.raises(ValueError):
+        resolve_precision("fp8", None, None)
+
+
 def test_generator_protocol_errors_without_gpu():
     import torch
     from emotivoice_amd.engine import EVError
