@@ -24,11 +24,12 @@ template <int K>
 struct Conv64MxGeom {
     static constexpr int C = 64, NB = 32, KG = (K + 1) / 2, KP = KG * 2;
     static constexpr int XROWS = 320, EPITCH = NB * 4 + 16;
+    static constexpr int XHC = XROWS * 64 + 64;        // one K-chunk of the slab's hi plane (+ 64 B: the two chunks a staging store writes land in different banks)
     static constexpr int WHB = K * NB * 64;            // one 32-channel K-chunk of the fp16 weights (two chunks)
     static constexpr int WQB = KP * NB * 32;           // one fp4 code plane
     static constexpr int WSB = KP * NB * 2;            // its scale bytes
     static constexpr int OFF_WH = 0, OFF_WQ = 2 * WHB, OFF_WS = OFF_WQ + 2 * WQB, OFF_XH = OFF_WS + 2 * WSB;
-    static constexpr int OFF_XQ = OFF_XH + 2 * XROWS * 64, OFF_XS = OFF_XQ + 2 * XROWS * 32, OFF_ES = OFF_XS + 2 * XROWS * 4;
+    static constexpr int OFF_XQ = OFF_XH + 2 * XHC, OFF_XS = OFF_XQ + 2 * XROWS * 32, OFF_ES = OFF_XS + 2 * XROWS * 4;
     static constexpr int TOTAL = OFF_ES + 8 * 16 * EPITCH;
     static_assert(OFF_XH % 16 == 0 && OFF_XQ % 16 == 0 && OFF_ES % 16 == 0 && TOTAL <= 160 * 1024, "LDS plan");
 };
@@ -40,10 +41,14 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
     constexpr int NB = G::NB, KG = G::KG, XROWS = G::XROWS, EPITCH = G::EPITCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Wh = smem + G::OFF_WH;        // [chunk][tap * 32 + co][64 B] swizzled
-    char* const Wq = smem + G::OFF_WQ;        // [plane][tap * 32 + co][32 B], halves swapped where (co >> 3) & 1
+    char* const Wq = smem + G::OFF_WQ;        // [plane][tap * 32 + co][32 B]
     char* const Wsc = smem + G::OFF_WS;       // [plane][tap * 32 + co][2]
     char* const Xh = smem + G::OFF_XH;        // [chunk][row][64 B] swizzled
-    char* const Xq = smem + G::OFF_XQ;        // [plane][row][32 B], halves swapped where (row >> 3) & 1
+    char* const Xq = smem + G::OFF_XQ;        // [plane][row][32 B]
+    // (code planes, 32-byte rows: a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} ... = fragment rows {0-3, 12-15} of channel half 0 with
+    // rows {4-11} of half 1 (and vice versa): rows r and r + 8 share a 32-byte bank range but always ask for different halves, so the plain layout
+    // is conflict-free.  The first version swapped the halves of every second group of 8 rows -- right for 16 consecutive lanes, wrong for the real
+    // groups: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.26 on this kernel, LDS busy half of the time)
     char* const Xsc = smem + G::OFF_XS;       // [plane][row][4] (two bytes used: the row's two 32-channel blocks)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char* const es = smem + G::OFF_ES + wave * 16 * EPITCH;
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
         // planes: host layout [plane][half n0/32][KP][32 co][32 B], then scales [plane][half][KP][32][2]
         const char* wm = reinterpret_cast<const char*>(p.W_mx);
         for (int c = tid; c < 2 * G::WQB / 16; c += 512) {
-            const int pl = c / (G::WQB / 16), r = c % (G::WQB / 16), row = r >> 1, hf = r & 1, co = row & 31;
-            *reinterpret_cast<uint4*>(Wq + pl * G::WQB + row * 32 + ((hf ^ ((co >> 3) & 1)) << 4)) =
+            const int pl = c / (G::WQB / 16), r = c % (G::WQB / 16), row = r >> 1, hf = r & 1;
+            *reinterpret_cast<uint4*>(Wq + pl * G::WQB + row * 32 + (hf << 4)) =
                 *reinterpret_cast<const uint4*>(wm + (size_t)(pl * 2 + (n0 >> 5)) * G::WQB + (size_t)r * 16);
         }
         for (int c = tid; c < 2 * G::WSB / 16; c += 512) {
@@ -139,10 +144,10 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                    \
             const int r_ = (tid >> 3) + 64 * i;                                                            \
-            *reinterpret_cast<u32x4*>(Xh + ((tid >> 2) & 1) * XROWS * 64 + swz(r_, tid & 3)) = xh[i];      \
+            *reinterpret_cast<u32x4*>(Xh + ((tid >> 2) & 1) * G::XHC + swz(r_, tid & 3)) = xh[i];      \
         }                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                      \
-            *reinterpret_cast<u32x4*>(Xq + cpl[j] * XROWS * 32 + crow[j] * 32 + ((chalf ^ ((crow[j] >> 3) & 1)) << 4)) = xc[j]; \
+            *reinterpret_cast<u32x4*>(Xq + cpl[j] * XROWS * 32 + crow[j] * 32 + (chalf << 4)) = xc[j];                           \
         *reinterpret_cast<u32x4*>(Xsc + spl * XROWS * 4 + srow * 4) = xs4;                                 \
     }
 
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
                 for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Wh + ch * G::WHB + swz(t * 32 + a * 16 + fr, fq));
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    uint4 xf = *reinterpret_cast<const uint4*>(Xh + ch * XROWS * 64 + xo + b * 16 * 64);
+                    uint4 xf = *reinterpret_cast<const uint4*>(Xh + ch * G::XHC + xo + b * 16 * 64);
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf), acc[a][b], 0, 0, 0);
@@ -220,13 +225,13 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int wr = tw * 32 + a * 16 + fr;
-                    wq[a] = *reinterpret_cast<const uint4*>(Wq + pl * G::WQB + wr * 32 + ((hf ^ (((a * 16 + fr) >> 3) & 1)) << 4));
+                    wq[a] = *reinterpret_cast<const uint4*>(Wq + pl * G::WQB + wr * 32 + (hf << 4));
                     ws[a] = *reinterpret_cast<const uint8_t*>(Wsc + pl * G::WSB + wr * 2 + hf);
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int rr = rq + b * 16;
-                    xq[b] = *reinterpret_cast<const uint4*>(Xq + pl * XROWS * 32 + rr * 32 + ((hf ^ ((rr >> 3) & 1)) << 4));
+                    xq[b] = *reinterpret_cast<const uint4*>(Xq + pl * XROWS * 32 + rr * 32 + (hf << 4));
                     xs[b] = *reinterpret_cast<const uint8_t*>(Xsc + pl * XROWS * 4 + rr * 4 + hf);
                 }
 #pragma unroll
