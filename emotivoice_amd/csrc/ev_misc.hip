@@ -694,17 +694,18 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_kernel(const AttnParams
 // bound (the MFMAs are 5 % of it).  Here a block of four waves (64 queries) stages 32 keys at a time: 768 float4 loads, split ONCE into fp16
 // hi / lo planes in the operand layouts -- K row-major [key][48] (pitch 104 B: conflict-free 8-byte fragment reads), V transposed [d][key]
 // (pitch 72 B) --, double-buffered, one barrier per stage; a wave's fragments are twelve ds_read_b64 per 16 keys.
-template <int DK>
-__global__ __launch_bounds__(256) void attention_mfma_x3_lds_kernel(const AttnParams p) {
+// NW waves per block = 16 NW queries per staged K / V tile: 8 waves halve the staging (global loads, hi / lo splits, LDS stores, barriers) per query
+template <int DK, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_mfma_x3_lds_kernel(const AttnParams p) {
     static_assert(DK == 48, "d_k = 48: 12 float4 per row, 3 reduction steps of 16, 3 output tiles of 16");
-    constexpr int NS = DK / 16, ND = DK / 16, KT = 32, KP = 104, VP = 72;
+    constexpr int NS = DK / 16, ND = DK / 16, KT = 32, KP = 104, VP = 72, NT = 64 * NW, NJ = (768 + NT - 1) / NT;
     constexpr int KB = KT * KP, VB = DK * VP, STAGE = 2 * KB + 2 * VB;       // K hi, K lo, Vt hi, Vt lo
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
     const int b = blockIdx.z, h = blockIdx.y;
     const int len = p.seq_len[b];
-    if ((int)blockIdx.x * 64 >= len) return;
+    if ((int)blockIdx.x * 16 * NW >= len) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * 16 * NW + wave * 16;
     const int fr = lane & 15, g = lane >> 4;
     const long row0 = p.seq_off[b];
     const float* base = reinterpret_cast<const float*>(p.qkv);
@@ -723,20 +724,25 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_lds_kernel(const AttnPa
             split4(x, qh[c], ql[c]);
         }
     }
-    // staging roles: unit u = tid + 256 j, j = 0..2; u < 384: K unit (key u / 12, float4 u % 12), else V unit u - 384
-    int ukey[3], uc4[3];
-    bool uv[3];
+    // staging roles: unit u = tid + NT j (768 units per stage); u < 384: K unit (key u / 12, float4 u % 12), else V unit u - 384
+    int ukey[NJ], uc4[NJ];
+    bool uv[NJ], uon[NJ];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { int u = tid + 256 * j; uv[j] = u >= 384; if (uv[j]) u -= 384; ukey[j] = u / 12; uc4[j] = u % 12; }
-    float4 st[3];
+    for (int j = 0; j < NJ; ++j) {
+        int u = tid + NT * j;
+        uon[j] = u < 768;                      // (wave-uniform: 768 is a multiple of 64)
+        u = min(u, 767);
+        uv[j] = u >= 384; if (uv[j]) u -= 384; ukey[j] = u / 12; uc4[j] = u % 12;
+    }
+    float4 st[NJ];
     const int nstage = (len + KT - 1) / KT;
 #define EV_ATL_LOAD(S)                                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                      \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                                     \
         const int kr_ = min((S) * KT + ukey[j], len - 1);                                                                \
         st[j] = *reinterpret_cast<const float4*>(base + (row0 + kr_) * p.ld + (uv[j] ? 2 : 1) * p.C + h * DK + uc4[j] * 4); \
     }
 #define EV_ATL_STORE(BUF)                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                      \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) if (uon[j]) {                                                         \
         const float x_[4] = {st[j].x, st[j].y, st[j].z, st[j].w};                                                        \
         h4 hi_, lo_;                                                                                                     \
         split4(x_, hi_, lo_);                                                                                            \
@@ -823,8 +829,13 @@ __global__ __launch_bounds__(256) void attention_mfma_x3_lds_kernel(const AttnPa
 void launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.dtype == DT_F32S && p.C / p.heads == 48) {          // fp32 rows, split-precision products (decoder, strict / mx modes)
         static const bool no_lds = getenv("EV_ATTN_X3_NOLDS") != nullptr;     // A/B switch: every wave fetches and splits its own tiles
+        static const char* nw_env = getenv("EV_ATTN_X3_NW");                   // A/B switch: "4" = 64 queries per block
         if (no_lds) hipLaunchKernelGGL((attention_mfma_x3_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((attention_mfma_x3_lds_kernel<48>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+        else if ((nw_env && nw_env[0] == '4') || p.max_len <= 64)
+            hipLaunchKernelGGL((attention_mfma_x3_lds_kernel<48, 4>), dim3((p.max_len + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+        else if ((nw_env && nw_env[0] == '8') || p.max_len <= 128)
+            hipLaunchKernelGGL((attention_mfma_x3_lds_kernel<48, 8>), dim3((p.max_len + 127) / 128, p.heads, p.B), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((attention_mfma_x3_lds_kernel<48, 16>), dim3((p.max_len + 255) / 256, p.heads, p.B), dim3(1024), 0, s, p);
         return;
     }
     if (p.dtype == DT_F16) {
