@@ -62,8 +62,21 @@ def mx_quant(v, fmt, dim):
 
 
 class Recipe:
-    def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh")):
+    def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None):
         self.name, self.cross, self.res32, self.op32, self.lo_terms = name, cross, res32, op32, lo_terms
+        # res_planes: the residual stream exists ONLY as the plane set of leaky_relu(x, .1) its consumers read anyway: fp16 hi plane + the
+        # remainder in this format ("f16" = a second fp16 plane, "fp4" / "fp6" = the MX code plane itself); None = a separate fp32 tensor
+        self.res_planes = res_planes
+
+
+def planes_roundtrip(x, fmt):
+    """x -> a = leaky_relu(x, .1) -> fp16(a) + Q(a - fp16(a)) -> leaky_relu^-1: what a consumer reconstructs from the plane set."""
+    a = F.leaky_relu(x, 0.1)
+    h = r16(a)
+    lo = a - h
+    lo = r16(lo) if fmt == "f16" else mx_quant(lo, fmt, 1)
+    a2 = h + lo
+    return torch.where(a2 >= 0, a2, a2 * 10.0)
 
 
 def conv_mx(x, w, b, rc, transposed=False, **kw):
@@ -88,6 +101,8 @@ def conv_mx(x, w, b, rc, transposed=False, **kw):
 
 def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
     st = (lambda t: t) if rc.res32 else r16              # residual-stream / stage tensors
+    if rc.res_planes:
+        st = lambda t: planes_roundtrip(t, rc.res_planes)
     so = (lambda t: t) if rc.op32 else r16               # conv1 -> conv2 intermediates (operand-only tensors)
 
     def conv(x, name, **kw):
@@ -156,6 +171,9 @@ def main():
             Recipe("+ MX-fp6 cross terms, fp32 storage", "fp6"),
             Recipe("+ MX-fp4 cross terms, fp32 storage", "fp4"),
             Recipe("+ MX-fp4 cross terms, fp16 residual stream", "fp4", res32=False),
+            Recipe("+ MX-fp4 cross terms, residual = hi plane + fp16 remainder plane", "fp4", res_planes="f16"),
+            Recipe("+ MX-fp4 cross terms, residual = hi plane + fp6 remainder codes", "fp4", res_planes="fp6"),
+            Recipe("+ MX-fp4 cross terms, residual = hi plane + fp4 remainder codes", "fp4", res_planes="fp4"),
             Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
             Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
         ]
