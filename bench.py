@@ -38,8 +38,9 @@ VOC_STAGE3_RB_FLOP_PER_FRAME = (9.437 + 22.020 + 34.603) * 1e6   # stage-3 ResBl
 VOC_STAGE2_K3_RB_FLOP_PER_FRAME = 18.874e6         # stage-2 k = 3 ResBlock (C = 64): run by the C = 64 fused pair kernel (fast mode)
 VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
 # the mx mode's own layer-wise contract: plane sets of 3.0625 B per element between the >= 64-channel layers (conv1 of a pair:
-# planes in / planes out; conv2: planes + fp32 residual in, fp32 + planes out), fp32 running MRF sums, the fused C = 32 pairs at 8 B per element
-VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": 4.310e6}
+# planes in / planes out; conv2: planes + the residual's hi plane / remainder codes / scales (2.53 B) in, planes out -- fp32 only out of the last conv of
+# a ResBlock), fp32 running MRF sums, the fused C = 32 pairs at 8 B per element.  (With fp32 residual streams, EV_MX_RES32=1, it was 4.310 MB.)
+VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": 3.551e6}
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_MFMA_FP4 = 10000.0                            # TFLOP/s dense, block-scaled fp4 / fp6 (MI355X_MICROARCH.md)
@@ -239,7 +240,7 @@ def roofline_block(eng, work, torch, strict=None):
                                            hbm_contract_frac=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
                                            hbm_contract_bytes_per_frame=VOC_BYTES_PER_FRAME_BY_MODE[mode],
                                            hbm_contract_note="this mode's layer-wise byte contract (fp16: 2.026 MB / frame; split precision: fp32 tensors, 2x; "
-                                                             "mx: plane sets + fp32 residual streams, 4.31 MB / frame)"))
+                                                             "mx: plane sets, residuals rebuilt from them, 3.55 MB / frame)"))
         if voc_pmc:
             roof["all_vocoder_convs"].update(hbm_pmc_bytes_per_frame=round(voc_pmc, 1), hbm_pmc_GBps=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9, 1),
                                              hbm_pmc_frac=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
