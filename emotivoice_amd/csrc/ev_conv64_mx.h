@@ -34,8 +34,10 @@ struct Conv64MxGeom {
     static_assert(OFF_XH % 16 == 0 && OFF_XQ % 16 == 0 && OFF_ES % 16 == 0 && TOTAL <= 160 * 1024, "LDS plan");
 };
 
-// MODE: 0 = plain (bias + optional leaky-relu), 1 = + fp32 residual and out_scale, 2 = + fp32 accumulate-in (may alias out32)
-template <int K, int MODE>
+// MODE: 0 = plain (bias + optional leaky-relu), 1 = + residual and out_scale, 2 = + fp32 accumulate-in (may alias out32)
+// RPL (MODE >= 1): the residual is the plane set conv1 of the pair read (ConvGemmParams::res_x4 ...: fp16 hi plane + fp4 remainder codes + scale
+// bytes, 2.5 bytes per element) instead of an fp32 tensor
+template <int K, int MODE, bool RPL = false>
 __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParams p) {
     using G = Conv64MxGeom<K>;
     constexpr int NB = G::NB, KG = G::KG, XROWS = G::XROWS, EPITCH = G::EPITCH;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
     const int abl = p.reserved0 >> 4;
     const f32x2 mxo_slope2 = f32x2{p.mxo_slope, p.mxo_slope};
     const bool mxo_act = p.mxo_slope != 1.0f, scaled = p.out_scale != 1.0f;          // (x * 1 is exact)
+    const f32x2 res_inv2 = f32x2{p.res_inv_slope, p.res_inv_slope};
     float* const o32 = p.out32;
     const uint8_t* vptr = p.row_valid ? p.row_valid : g_row_always_valid;
     const int vshift = p.row_valid ? p.valid_shift : 31;
@@ -173,10 +176,16 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
         // ---------------- memory requests of this item, oldest first
         uint8_t vb = vptr[(m0 + wave * 32 + (lane & 31)) >> vshift];
         float4 resv[2][2], accin[2][2];
+        u32x4 rph[2];
+        unsigned rpc[2], rps[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const long t = m0 + wave * 32 + it * 16 + er;
-            if constexpr (MODE >= 1) {
+            if constexpr (MODE >= 1 && RPL) {
+                rph[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.res) + (t * 64 + eco) * 2);
+                rpc[it] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p.res_x4) + t * 32 + (n0 >> 5) * 16 + eg * 4);
+                rps[it] = reinterpret_cast<const uint8_t*>(p.res_xs)[t * 4 + (n0 >> 5)];
+            } else if constexpr (MODE >= 1) {
                 const float* rp = reinterpret_cast<const float*>(p.res) + t * p.ldres + eco;
                 resv[it][0] = *reinterpret_cast<const float4*>(rp); resv[it][1] = *reinterpret_cast<const float4*>(rp + 4);
             }
@@ -274,8 +283,23 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
                 for (int q = 0; q < 4; ++q) v[q] = lrelu2(v[q], act_slope2);
             }
             if constexpr (MODE >= 1) {
-                const f32x2 rr[4] = {f32x2{resv[it][0].x, resv[it][0].y}, f32x2{resv[it][0].z, resv[it][0].w},
-                                     f32x2{resv[it][1].x, resv[it][1].y}, f32x2{resv[it][1].z, resv[it][1].w}};
+                f32x2 rr[4];
+                if constexpr (RPL) {          // x = lrelu^-1(hi + code * scale) = min(a, a * inv)
+                    const half2v* h = reinterpret_cast<const half2v*>(&rph[it]);
+                    const float sc = __uint_as_float(rps[it] << 23);
+                    rr[0] = __builtin_convertvector(h[0], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 0);
+                    rr[1] = __builtin_convertvector(h[1], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 1);
+                    rr[2] = __builtin_convertvector(h[2], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 2);
+                    rr[3] = __builtin_convertvector(h[3], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 3);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 t2 = rr[q] * res_inv2;
+                        rr[q] = f32x2{min_raw(rr[q][0], t2[0]), min_raw(rr[q][1], t2[1])};
+                    }
+                } else {
+                    rr[0] = f32x2{resv[it][0].x, resv[it][0].y}; rr[1] = f32x2{resv[it][0].z, resv[it][0].w};
+                    rr[2] = f32x2{resv[it][1].x, resv[it][1].y}; rr[3] = f32x2{resv[it][1].z, resv[it][1].w};
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += rr[q];
                 if (scaled) {
@@ -349,6 +373,8 @@ static hipError_t conv64_mx_attr() {
     r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
     r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
     r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
     return e;
 }
 static hipError_t conv64_mx_set_attributes() {
@@ -366,7 +392,8 @@ static bool conv64_mx_eligible(const ConvGemmParams& p) {
            p.center * 2 == p.taps - 1 && p.mx_x4[0] && p.mx_x4[1] && p.mx_xs[0] && p.mx_xs[1] && !p.pro_lrelu && (p.out32 || p.mxo_h) && !p.out16 && !p.seq_bias &&
            !p.add16_a && !p.post_lrelu && !p.out32_before_post && !rare_act && (!p.out32 || p.ldo == 64) &&
            (!p.mxo_h || (p.mxo_logC == 6 && p.mxo_q4[0] && p.mxo_q4[1] && p.mxo_qs[0] && p.mxo_qs[1] && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f)) &&
-           (!p.res || p.res_dtype == DT_F32) && (!p.acc32 || p.res) && (!p.res || p.act == ACT_NONE) &&
+           (!p.res || p.res_dtype == DT_F32 || (p.res_dtype == DT_MX && p.res_x4 && p.res_xs && p.ldres == 64 && p.res_inv_slope >= 1.0f)) &&
+           (!p.acc32 || p.res) && (!p.res || p.act == ACT_NONE) &&
            !(p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f));
 }
 static void launch_conv64_mx(const ConvGemmParams& p, hipStream_t s) {
@@ -374,8 +401,11 @@ static void launch_conv64_mx(const ConvGemmParams& p, hipStream_t s) {
     const int nitems = ((p.M / 256 + 7) / 8) * 16;
     const int grid = nitems <= n_cu ? nitems : (n_cu / 16) * 16;           // a multiple of 16 keeps a block's channel half fixed
     const int mode = p.acc32 ? 2 : (p.res ? 1 : 0);
+    const bool rpl = p.res && p.res_dtype == DT_MX;
 #define EV_C64_LAUNCH(KK)                                                                                                        \
-        if (mode == 2) hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 2>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p);      \
+        if (mode == 2 && rpl) hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 2, true>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p);      \
+        else if (mode == 1 && rpl) hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 1, true>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p); \
+        else if (mode == 2) hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 2>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p); \
         else if (mode == 1) hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 1>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p); \
         else hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 0>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p);
     switch (p.taps) {

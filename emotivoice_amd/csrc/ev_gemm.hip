@@ -54,6 +54,11 @@ __device__ __forceinline__ float max_raw(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // max(|a|, |b|, m) in one VALU (source modifiers), m >= 0: the block maxima of mx_quant8 took an and + a max per element before
 __device__ __forceinline__ float max3_abs_raw(float a, float b, float m) {
     float r;
@@ -278,8 +283,10 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 // LEAN: the operands of a pass are requested at the top of THAT pass instead of one pass ahead (one register set instead of two:
 // the MRF variant of the 128-register phased kernel, whose epilogue is covered by the CU's other block anyway).
 // MXP: additionally (or, without O32 / O16, only) the MX plane set of lrelu(result, mxo_slope) for a DT_MX consumer (mx_emit_planes).
+// RESPL: the residual comes from a plane set (ConvGemmParams::res_x4 ...): fp16 hi plane + fp4 codes of the remainder + their block scales, 2.5 bytes
+// per element instead of 4, and no fp32 copy of the residual stream has to be written by its producer.
 enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64, EPI_ADD16 = 128, EPI_LEAN = 256,
-       EPI_MXP = 512 };
+       EPI_MXP = 512, EPI_RESPL = 1024 };
 
 // ---- MX plane set of an activation (format: ev_gemm_mx.h / emotivoice_amd/mxfp4.py).  E8M0 byte of the block scale 2^(floor(log2 amax) - 2),
 // clamped to [1, 254] (an all-zero block gets 1).
@@ -375,6 +382,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     for (int pass = 0; pass < NP; ++pass) vld[pass] = vptr[(t0 + pass * 32 + (lane & 31)) >> vshift];
     uint4 r16[2][IT], a16[2][IT][2];
     float4 r32[2][IT][2], a32[2][IT][2];
+    uint4 rph[2][IT];                       // EPI_RESPL: 8 fp16 hi parts, 8 fp4 remainder codes, the block's scale byte
+    unsigned rpc[2][IT], rps[2][IT];
+    long rp_soff = 0;
+    if constexpr (EPI & EPI_RESPL) rp_soff = (long)(co >> 7) * p.res_xs_stride + ((co >> 5) & 3);
     constexpr bool LEAN = (EPI & EPI_LEAN) != 0;
 #define EV_EPI_SET(PASS) (LEAN ? 0 : ((PASS) & 1))
 #define EV_EPI_PREFETCH(PASS)                                                                                              \
@@ -386,6 +397,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             const float* rp_ = reinterpret_cast<const float*>(p.res) + t_ * p.ldres + co;                                  \
             r32[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const float4*>(rp_);                                          \
             r32[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const float4*>(rp_ + 4);                                      \
+        }                                                                                                                  \
+        if constexpr (EPI & EPI_RESPL) {                                                                                   \
+            const long lin_ = t_ * p.ldres + co;                                                                           \
+            rph[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.res) + lin_ * 2);  \
+            rpc[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p.res_x4) + (lin_ >> 1)); \
+            rps[EV_EPI_SET(PASS)][it] = reinterpret_cast<const uint8_t*>(p.res_xs)[rp_soff + t_ * 4];                      \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ACC32) {                                                                                   \
             const float* ap_ = p.acc32 + t_ * p.ldacc + co;                                                                \
@@ -419,6 +436,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     const bool has_post = p.post_lrelu != 0;
     const f32x2 post_slope2 = f32x2{p.post_slope, p.post_slope};
     const f32x2 mxo_slope2 = f32x2{p.mxo_slope, p.mxo_slope};
+    const f32x2 res_inv2 = f32x2{p.res_inv_slope, p.res_inv_slope};
     const bool mxo_act = p.mxo_slope != 1.0f, scaled = p.out_scale != 1.0f;          // (x * 1 is exact: skipping it changes no bit)
     __half* const o16 = reinterpret_cast<__half*>(p.out16);
     float* const o32a = p.out32_before_post ? p.out32 : nullptr;
@@ -488,6 +506,22 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             if constexpr (EPI & EPI_RES32) {
                 const float4 r0 = r32[EV_EPI_SET(pass)][it][0], r1 = r32[EV_EPI_SET(pass)][it][1];
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
+            }
+            if constexpr (EPI & EPI_RESPL) {
+                // a' = hi + code * 2^(scale - 127) is the plane set's value of lrelu(x, 1 / inv): x = min(a', a' * inv) undoes it (inv >= 1)
+                const half2v* h = reinterpret_cast<const half2v*>(&rph[EV_EPI_SET(pass)][it]);
+                const unsigned cw = rpc[EV_EPI_SET(pass)][it];
+                const float sc = __uint_as_float(rps[EV_EPI_SET(pass)][it] << 23);
+                f32x2 a[4];
+                a[0] = __builtin_convertvector(h[0], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 0);
+                a[1] = __builtin_convertvector(h[1], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 1);
+                a[2] = __builtin_convertvector(h[2], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 2);
+                a[3] = __builtin_convertvector(h[3], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 t = a[j] * res_inv2;
+                    v[j] += f32x2{min_raw(a[j][0], t[0]), min_raw(a[j][1], t[1])};
+                }
             }
             if (scaled) {
 #pragma unroll

@@ -336,10 +336,16 @@ static int mx_epi_variant(const ConvGemmParams& p) {
                  (p.mxo_logC == 0 || (p.mxo_logC >= 6 && p.mxo_logC <= 12 && p.N % (1 << p.mxo_logC) == 0)))) return -1;
     if (mxp && rare_act && !p.out32 && !p.res && !p.acc32 && !p.seq_bias && !p.add16_a && !p.out16 && !p.post_lrelu)
         return EPI_RARE_ACT | EPI_MXP;                                       // conv-FFN's first conv: erf-GELU, planes only
-    if (p.seq_bias || p.add16_a || p.out16 || p.out32_before_post || p.post_lrelu || odd_slope || rare_act) return mxp ? -1 : EPI_GENERIC;
+    const bool respl = p.res && p.res_dtype == DT_MX;          // residual from a plane set (fp16 hi plane + fp4 remainder codes + scales)
+    if (p.seq_bias || p.add16_a || p.out16 || p.out32_before_post || p.post_lrelu || odd_slope || rare_act) return (mxp || respl) ? -1 : EPI_GENERIC;
     const bool res32 = p.res && p.res_dtype == DT_F32;
-    if (p.res && !res32) return mxp ? -1 : EPI_GENERIC;
     const int m = mxp ? EPI_MXP : 0;
+    if (respl) {
+        if (!(p.res_x4 && p.res_xs && p.ldres == p.N && p.res_inv_slope >= 1.0f)) return -1;
+        if (!p.out32) return (mxp && !p.acc32) ? (EPI_RESPL | EPI_LEAN | EPI_MXP) : -1;          // conv2 of a pair inside a ResBlock: planes only
+        return p.acc32 ? (EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | m) : (EPI_RESPL | EPI_O32 | EPI_LEAN | m);
+    }
+    if (p.res && !res32) return mxp ? -1 : EPI_GENERIC;
     if (!p.out32) return (mxp && !p.res && !p.acc32) ? EPI_MXP : -1;
     if (!p.acc32 && !p.res) return EPI_O32 | m;
     if (!p.acc32 && res32) return EPI_RES32 | EPI_O32 | EPI_LEAN | m;
@@ -347,7 +353,9 @@ static int mx_epi_variant(const ConvGemmParams& p) {
     return mxp ? -1 : EPI_GENERIC;
 }
 #define EV_MX_VARIANTS(X) X(EPI_O32) X(EPI_RES32 | EPI_O32 | EPI_LEAN) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_MXP) X(EPI_O32 | EPI_MXP) \
-    X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RARE_ACT | EPI_MXP) X(EPI_GENERIC)
+    X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RARE_ACT | EPI_MXP) X(EPI_GENERIC)   \
+    X(EPI_RESPL | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_O32 | EPI_LEAN | EPI_MXP)                                    \
+    X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP)
 template <int TAPS>
 static void launch_mx_taps(const ConvGemmParams& p, int e, hipStream_t s) {
     switch (e) {
@@ -388,9 +396,9 @@ static bool mx_eligible(const ConvGemmParams& p) {
 // 0 = this DT_MX call can run (as the MX kernel, or -- fp32 input, no plane output -- as the split-precision fallback)
 static bool conv64_mx_eligible(const ConvGemmParams& p);
 int mx_check(const ConvGemmParams& p) {
-    if (p.dtype != DT_MX) return p.mxo_h || mx_planes_in(p) ? -1 : 0;       // plane sets exist only between DT_MX launches
+    if (p.dtype != DT_MX) return p.mxo_h || mx_planes_in(p) || (p.res && p.res_dtype == DT_MX) ? -1 : 0;       // plane sets exist only between DT_MX launches
     if (mx_eligible(p) || conv64_mx_eligible(p)) return 0;
-    return (p.mxo_h || mx_planes_in(p) || !p.W_lo) ? -1 : 0;
+    return (p.mxo_h || mx_planes_in(p) || !p.W_lo || (p.res && p.res_dtype == DT_MX)) ? -1 : 0;
 }
 static void launch_mx(const ConvGemmParams& p_in, hipStream_t s) {
     ConvGemmParams p = p_in;

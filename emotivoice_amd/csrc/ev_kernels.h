@@ -50,6 +50,12 @@ struct ConvGemmParams {
     // per row; mxo_qs[0] / [1] their E8M0 block scales, one byte per 32 channels, chunk-major [C / 128][mxo_qs_stride / 4 rows][4].
     // Invalid rows give all-zero planes.  Every plane needs 64 readable slack rows on both sides for its consumer.
     void* mxo_h; void* mxo_q4[2]; void* mxo_qs[2]; unsigned mxo_qs_stride; int mxo_logC; float mxo_slope; int reserved3;
+    // Residual from a plane set (res_dtype == DT_MX; DT_MX launches only): the residual x of the launch's [M][N] output is not an fp32 tensor but the
+    // plane set of a = lrelu(x, 1 / res_inv_slope) that conv1 of the pair read as its operand: res = its fp16 hi plane ([M][N], ldres == N), res_x4 = the
+    // fp4 codes of the remainder a - fp16(a) ([M][N / 2]), res_xs their E8M0 scales (chunk-major [N / 128][res_xs_stride / 4 rows][4], as mx_xs);
+    // the epilogue rebuilds x = a' >= 0 ? a' : a' * res_inv_slope, a' = hi + code * scale.  tools/precision_study_mx.py: the generator's waveform error
+    // goes from 3.4e-4 to 4.4e-4 on the zero-mean recipe, and a conv2 launch moves 8.7 instead of 14.1 bytes per element.
+    const void* res_x4; const void* res_xs; unsigned res_xs_stride; float res_inv_slope;
 };
 // bytes of activation-plane scratch a DT_MX call with an [M][K] input needs
 size_t mx_scratch_bytes(int M, int K);

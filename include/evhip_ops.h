@@ -48,6 +48,10 @@ typedef struct ev_conv_gemm_desc {
     /* plane-set output (dtype 3): planes of lrelu(result, mxo_slope) as [rows][2^mxo_logC]: fp16 hi plane, fp4 code planes of the hi / lo
        parts, their scale planes [C/128][mxo_qs_stride/4][4]; all NULL = none.  emotivoice_amd/mxfp4.py states the contents. */
     void* mxo_h; void* mxo_q4[2]; void* mxo_qs[2]; unsigned mxo_qs_stride; int mxo_logC; float mxo_slope; int reserved3;
+    /* res_dtype 3 (dtype 3 only): the residual is the plane set of lrelu(x, 1 / res_inv_slope): res = its fp16 hi plane [M][N] (ldres == N),
+       res_x4 = the fp4 codes of the remainder [M][N / 2], res_xs their E8M0 scales [N / 128][res_xs_stride / 4][4]; x = hi + code * scale,
+       negative values times res_inv_slope */
+    const void* res_x4; const void* res_xs; unsigned res_xs_stride; float res_inv_slope;
 } ev_conv_gemm_desc;
 
 int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* hip_stream);

@@ -964,3 +964,102 @@ def test_conv_c64_mx(lib, k, dil, mode, M):
             assert _rel(rec, refs["emu"]) < 1e-4, (k, dil, mode, _rel(rec, refs["emu"]))
             assert _rel(gh.double(), refs["emu"]) < 6e-4 and not ps.h[PAD:PAD + M].cpu().numpy()[~vr.numpy()].any()
     assert _rel(refs["emu"], refs["exact"]) > 1e-6
+
+
+def _host_plane_set(a):
+    """a [R][C] fp32 cpu (R = M + 2 PAD) -> a _PlaneSet holding the host quantiser's planes of a, and the parts (hi, Q(hi), Q(lo)) in fp64."""
+    R, Cc = a.shape
+    hi64, qh64, ql64, (h16, ch, cl, sh, sl) = _mx_act_parts(a)
+    ps = _PlaneSet(R - 2 * PAD, Cc)
+    ps.h.copy_(torch.from_numpy(h16))
+    for i, (codes, sb) in enumerate(((ch, sh), (cl, sl))):
+        ps.q4[i].copy_(torch.from_numpy(np.ascontiguousarray(codes)))
+        if Cc == 64:            # [1][rows][4], two bytes used
+            sb4 = np.concatenate([sb, np.ones((R, 2), np.uint8)], 1)[None]
+        else:                   # chunk-major [C / 128][rows][4]
+            sb4 = np.ascontiguousarray(sb.reshape(R, Cc // 128, 4).transpose(1, 0, 2))
+        ps.qs[i].copy_(torch.from_numpy(sb4))
+    return ps, (hi64, qh64, ql64)
+
+
+@pytest.mark.parametrize("Cc,k,dil,mode", [(128, 3, 1, "planes"), (128, 7, 3, "o32"), (128, 11, 1, "o32+planes"), (256, 3, 5, "acc"),
+                                           (256, 7, 1, "acc+planes"), (64, 3, 1, "planes"), (64, 7, 3, "o32+planes"), (64, 11, 5, "acc+planes"),
+                                           (64, 3, 5, "acc")])
+def test_mx_residual_from_planes(lib, Cc, k, dil, mode):
+    """res_dtype 3: conv2 of a ResBlock pair takes its residual from the plane set of lrelu(x, 0.1) that conv1 read -- x' = lrelu^-1(hi + Q4(lo)) --
+    instead of an fp32 tensor (conv_gemm_mx_kernel's EPI_RESPL epilogues at C = 128 / 256, conv_c64_mx_kernel<K, MODE, true> at C = 64).
+    Reference: the same arithmetic in fp64 with the host quantiser's planes; the fp32 output must match it tightly, a planes-only output must
+    reproduce it to the fp4 step of the remainder, planes beside an fp32 output must be the host quantiser of that output bit for bit."""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(900 + Cc + k + dil)
+    M = 256 * 5
+    R = M + 2 * PAD
+    valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
+    valid[:2] = 0
+    valid[70:73] = 0
+    vrow = valid.repeat_interleave(8).bool().cpu()
+    # operand (xt) and residual (x) activations; the plane sets hold lrelu(., slope) of them: slope 1 for xt (already activated), 0.1 for x
+    xt = torch.randn(R, Cc) * torch.exp(0.5 * torch.randn(R, 1))
+    xt[:PAD] = 0
+    xt[PAD + M:] = 0
+    x = torch.randn(R, Cc) * torch.exp(0.5 * torch.randn(R, 1))
+    ps_t, (th, tqh, tql) = _host_plane_set(xt)
+    ps_x, (xh, _, xql) = _host_plane_set(_lrelu(x, 0.1).float())
+    a_rec = xh + xql                                              # what the epilogue adds back: hi + Q4(lo), then the inverse leaky-relu
+    x_rec = torch.where(a_rec >= 0, a_rec, a_rec * 10.0)[PAD:PAD + M]
+    assert _rel(x_rec, x.double()[PAD:PAD + M]) < 2e-4
+    w = torch.randn(Cc, Cc, k) / math.sqrt(Cc * k)
+    bias = torch.randn(Cc, device="cuda") * 0.1
+    wg = w.permute(0, 2, 1).contiguous().numpy()
+    hi = wg.astype(np.float16)
+    lo16 = ((wg - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    if Cc == 64:
+        planes = mxfp4.pack_c64_weight_planes(wg)
+        ql, qh = mxfp4.c64_weight_planes_dequant(planes, k)
+    else:
+        planes = mxfp4.pack_weight_planes(wg)
+        ql, qh = mxfp4.weight_planes_dequant(planes, *wg.shape)
+    t64 = lambda z: torch.from_numpy(np.asarray(z, np.float64))          # noqa: E731
+    d_hi, d_lo, d_mx = torch.from_numpy(hi).cuda(), torch.from_numpy(lo16).cuda(), torch.from_numpy(planes).cuda()
+    acc = torch.randn(M, Cc, device="cuda")
+    want32, planes_out, acc_in = mode != "planes", "planes" in mode, mode.startswith("acc")
+    out = torch.full((M, Cc), 7.0, device="cuda")
+    ps_o = _PlaneSet(M, Cc)
+    d = _ffi.ev_conv_gemm_desc()
+    d.dtype, d.W, d.W_lo, d.W_mx = 3, d_hi.data_ptr(), d_lo.data_ptr(), d_mx.data_ptr()
+    ps_t.in_fields(d)
+    d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale, d.ldo = bias.data_ptr(), M, Cc, Cc, k, dil, (k - 1) // 2, 1.0 / 3.0, Cc
+    d.row_valid, d.valid_shift = valid.data_ptr(), 3
+    d.res, d.res_dtype, d.ldres = ps_x.h[PAD:].data_ptr(), 3, Cc
+    d.res_x4, d.res_xs, d.res_xs_stride, d.res_inv_slope = ps_x.q4[1][PAD:].data_ptr(), ps_x.qs[1][0, PAD:].data_ptr(), R * 4, 10.0
+    if acc_in:
+        d.acc32, d.ldacc = acc.data_ptr(), Cc
+    if want32:
+        d.out32 = out.data_ptr()
+    if planes_out:
+        ps_o.out_fields(d, 0.1)
+        if Cc == 64:
+            d.mxo_logC = 6
+    _launch(lib, d)
+    h = dil * (k - 1) // 2
+    rows = slice(PAD - h, PAD + M + h)
+    ref = _conv64(th[rows], t64(hi), dil, k) + _conv64(tqh[rows], t64(ql), dil, k) + _conv64(tql[rows], t64(qh), dil, k) + bias.double().cpu()
+    ref = (ref + x_rec) / 3.0 + (acc.double().cpu() if acc_in else 0.0)
+    ref[~vrow] = 0
+    if want32:
+        got = out.cpu().double()
+        assert float(out[~vrow.cuda()].abs().max()) == 0.0
+        assert _rel(got, ref) < 2e-6, (Cc, k, dil, mode, _rel(got, ref))
+    if planes_out:
+        sl_ = (lambda q: q[0, PAD:PAD + M, :2]) if Cc == 64 else (lambda q: q[:, PAD:PAD + M].permute(1, 0, 2).reshape(M, Cc // 32))
+        if want32:
+            _, _, _, (h16o, cho, clo, sho, slo) = _mx_act_parts(_lrelu(out.cpu(), 0.1))
+            assert np.array_equal(ps_o.h[PAD:PAD + M].cpu().numpy().view(np.uint16), h16o.view(np.uint16))
+            for i, (codes, sb) in enumerate(((cho, sho), (clo, slo))):
+                assert np.array_equal(ps_o.q4[i][PAD:PAD + M].cpu().numpy(), codes), i
+                assert np.array_equal(sl_(ps_o.qs[i]).cpu().numpy(), sb), i
+        else:
+            lo_rec = mxfp4.dequantize(ps_o.q4[1][PAD:PAD + M].cpu().numpy(), np.ascontiguousarray(sl_(ps_o.qs[1]).cpu().numpy()), 32)
+            rec = ps_o.h[PAD:PAD + M].float().cpu().double() + torch.from_numpy(lo_rec).double()
+            assert _rel(rec, _lrelu(ref, 0.1)) < 1e-4, (Cc, k, dil, mode, _rel(rec, _lrelu(ref, 0.1)))
+            assert not ps_o.h[PAD:PAD + M].cpu().numpy()[~vrow.numpy()].any()
