@@ -518,3 +518,4 @@ def test_chunked_stage_execution_is_bit_identical(gpu):
     assert float(np.abs(outs[0]).max()) > 0
     for other in outs[1:]:
         assert other.shape == outs[0].shape and np.array_equal(outs[0], other)
+
