@@ -39,7 +39,34 @@ VOC_STAGE2_K3_RB_FLOP_PER_FRAME = 18.874e6         # stage-2 k = 3 ResBlock (C =
 VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
 # the mx mode's own layer-wise contract: plane sets of 3.0625 B per element between the >= 64-channel layers (conv1 of a pair:
 # planes in / planes out; conv2: planes + fp32 residual in, fp32 + planes out), fp32 running MRF sums, the fused C = 32 pairs at 8 B per element
-VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": 4.310e6}
+def mx_contract_bytes_per_frame(residual_from_planes=True):
+    """Layer-wise HBM bytes per mel frame of the generator's OWN data flow in the mx mode (not SURVEY 8(d)'s numerator: that is VOC_BYTES_PER_FRAME,
+    reported as hbm_algorithmic_*).  P = 3.0625 B per element of a plane set (fp16 hi 2 + two fp4 code planes 0.5 + 0.5 + two E8M0 scales 1/32 each);
+    a residual rebuilt from planes reads hi + remainder codes + their scales = 2.53125 B; stages 0-2: every conv planes in / planes out, conv2
+    + residual, the last conv of a ResBlock + the fp32 running MRF sum; stage 3: fused pairs, fp32 in / out (8 B per element and pair)."""
+    P, R = 3.0625, 2.53125
+    E, Ein = [2048, 8192, 8192, 8192], [512, 2048, 8192, 8192]       # elements per mel frame of a stage's tensors / of its up-conv's input
+    b = 80 * 4 + 512 * 4 + 512 * 4 + 512 * P                         # conv_pre (fp32 in / out), its output's planes
+    for s in range(4):
+        e = E[s]
+        if s == 3:
+            b += Ein[s] * P + e * 4 + sum(3 * 8 * e + (4 * e if j else 0) for j in range(3))
+            continue
+        b += Ein[s] * P + e * P + (0 if residual_from_planes else 4 * e)
+        for j in range(3):
+            for d in range(3):
+                res = e * R if residual_from_planes else 4 * e
+                b += 2 * e * P + e * P + res                              # conv1 in / out, conv2 xt in + residual
+                if d < 2:
+                    b += e * P + (0 if residual_from_planes else 4 * e)
+                else:
+                    b += (4 * e if j else 0) + 4 * e + (e * P if j == 2 else 0)     # running MRF sum in / out (or the stage output + its planes)
+    return b + E[3] * 4 + 256 * 4                                    # conv_post
+
+
+# per-mode layer-wise contracts of the modes' own data flows (fp16: SURVEY 8(d); split precision: fp32 tensors; mx: 3.550 MB with the residual
+# rebuilt from planes -- the default since round 4 --, 4.310 MB with a separate fp32 residual tensor)
+VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": mx_contract_bytes_per_frame(True)}
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_MFMA_FP4 = 10000.0                            # TFLOP/s dense, block-scaled fp4 / fp6 (MI355X_MICROARCH.md)
@@ -48,7 +75,7 @@ DTYPE_NAME = {"f16": "f16", "x3": "f16x3 (fp16 hi/lo split, 3 MFMAs per product,
               "mx": "f16+mxfp4 (fp32 activations; per product one fp16 MFMA on the hi parts + two block-scaled fp4 MFMAs for the cross terms; "
                     "split-precision fp16x3 where channels < 128 and in the mel decoder)"}
 # measured DC-free relative L2 of the waveform against the reference's own outputs (tests/test_gpu_parity.py, profiles/r3_h_parity_report.json)
-PARITY_LEVEL = {"mx": "<= 4.4e-4 on every fixture incl. zero-mean and trained-like gains (bar 1e-3)", "fast": "2.4e-3 on zero-mean audio (bar 1e-3: NOT met)",
+PARITY_LEVEL = {"mx": "<= 5.5e-4 on every fixture incl. zero-mean and trained-like gains (bar 1e-3)", "fast": "2.4e-3 on zero-mean audio (bar 1e-3: NOT met)",
                 "strict": "<= 3e-6"}
 REFERENCE_CPU_FRAMES_PER_S = 628.0                 # the reference's own JETSGenerator, 8 Xeon cores, B = 1, N = 256
 
@@ -59,7 +86,19 @@ def decoder_flops(frames):
     return 2.0 * 4.0 * T * (4 * 384 ** 2 + 2 * T * 384 + 2 * 384 * 1536 * 3)
 
 
-def cpu_baseline(n_utts, phonemes):
+def csrc_hash():
+    """Content hash of the kernel sources: profiles/latest_hbm_traffic.json carries the hash it was measured on (tools/profile_summary.py), and
+    a `traffic` figure is only printed for the same sources (the GPU box has no .git, so a commit id cannot be read there)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "emotivoice_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(n_utts, phonemes, threads=16):
     """The CPU oracle (a port of the reference path) timed on this box's host cores: B = 1 per utterance,
     the only batch size the reference's call sites use."""
     import torch
@@ -68,7 +107,7 @@ def cpu_baseline(n_utts, phonemes):
     from emotivoice_amd.synthetic import synth_inputs, synth_state_dict
     # 256 torch threads on the GPU box's 2x64-core EPYC run ~100x slower than 16 (oversubscription); the reference
     # itself pins a handful of threads per worker (inference_tts.py:186 uses 4).  16 is what we time and report.
-    cores = min(os.cpu_count() or 1, int(os.environ.get("EV_CPU_THREADS", "16")))
+    cores = min(os.cpu_count() or 1, threads)
     torch.set_num_threads(cores)
     sd = to_torch_sd(synth_state_dict(0, "bench"))
     utts = synth_inputs(1, [phonemes] * (n_utts + 1), None)
@@ -173,7 +212,7 @@ VOC_FAMILIES = {
 DOMINANT = {"f16": "voc_conv_gemm_f16", "x3": "voc_conv_gemm_x3", "mx": "voc_conv_gemm_mx"}
 
 
-def roofline_block(eng, work, torch, strict=None):
+def roofline_block(eng, work, torch, dump=None):
     """One extra profiled step (hipEvents on the engine's stream around every launch, single stream) -> per-family accounting.
     `achieved` of the dominant family = the ALGORITHMIC FLOPs of exactly its launches (one product per multiply-add, transposed convs at
     their two real taps) / the sum of their hipEvent durations; `issued_equiv_*` scales that by the MFMA-equivalents the family's
@@ -184,8 +223,7 @@ def roofline_block(eng, work, torch, strict=None):
     stats = {s["name"]: s for s in eng.kernel_stats()}
     stages = eng.timings()
     mode = eng.vocoder_precision
-    dump = os.environ.get("EV_DUMP_LAUNCHES")             # per-launch table (kernel, shape, ms, TF/s, GB/s) for profiles/
-    if dump:
+    if dump:                                               # --dump-launches: per-launch table (kernel, shape, ms, TF/s, GB/s) for profiles/
         recs = eng.launch_records()
         for r in recs:
             r["TFLOPs"] = round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["ms"] > 0 and r["flops"] > 0 else None
@@ -213,14 +251,21 @@ def roofline_block(eng, work, torch, strict=None):
             voc_ms += st["ms"]
             voc_issued += u * st["flops"]
         voc_pmc = None               # PMC-measured HBM bytes of the whole generator per mel frame, this mode
-        traffic = tnote = None      # HBM bytes per launch of the dominant family from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
+        traffic = tcommit = None    # HBM bytes per launch of the dominant family from the PMC passes (separate rocprofv3 --pmc runs, see profiles/)
+        tnote = "no PMC passes for this workload / mode"
         tpath = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
         if os.path.exists(tpath) and work.mode == "am_vocoder" and B == 32:
-            t = json.load(open(tpath))
-            t = t.get(mode, t if mode == "f16" and "hbm_bytes_per_launch" in t else {})          # one entry per precision mode (tools/profile_summary.py)
-            traffic = t.get("hbm_bytes_per_launch")
-            voc_pmc = t.get("vocoder_hbm_bytes_per_frame")
-            tnote = "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes, profiles/latest_hbm_traffic.json"
+            tall = json.load(open(tpath))
+            t = tall.get(mode, tall if mode == "f16" and "hbm_bytes_per_launch" in tall else {})          # one entry per precision mode (tools/profile_summary.py)
+            tcommit = tall.get("csrc_hash")
+            if tcommit and tcommit == csrc_hash():
+                traffic = t.get("hbm_bytes_per_launch")
+                voc_pmc = t.get("vocoder_hbm_bytes_per_frame")
+                tnote = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes of these kernel sources "
+                         "(profiles/latest_hbm_traffic.json, csrc_hash matches)")
+            else:
+                tnote = ("profiles/latest_hbm_traffic.json was measured on other kernel sources (csrc_hash %s, now %s): stale, not reported -- "
+                         "re-run tools/run_profiles.sh" % (tcommit, csrc_hash()))
         # dense MFMA peak of the family's ARITHMETIC per algorithmic product: fp16 2.5 PF/s; split precision = three fp16 MFMAs -> 2.5 / 3;
         # mx = one fp16 MFMA (2.5 PF/s) + two fp4 MFMAs (10 PF/s, MI355X_MICROARCH.md) -> 1 / (1 / 2.5 + 2 / 10) = 1.667 PF/s
         peak = {1.0: PEAK_MFMA_F16, 3.0: PEAK_MFMA_F16 / 3.0, 1.5: 1.0 / (1.0 / PEAK_MFMA_F16 + 2.0 / PEAK_MFMA_FP4)}[units]
@@ -228,18 +273,23 @@ def roofline_block(eng, work, torch, strict=None):
                     achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(achieved / peak, 4),
                     peak_note="dense MFMA peak of this arithmetic per algorithmic product (fp16: 2500; 3 x fp16: 833; fp16 + 2 x fp4: 1667 TFLOP/s)",
                     frac_of_fp16_peak=round(achieved / PEAK_MFMA_F16, 4),
-                    traffic=traffic, traffic_note=tnote, launches=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+                    traffic=traffic, traffic_note=tnote, traffic_commit=tcommit, launches=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
                     algorithmic_flop_per_launch=round(dom["flops"] / dom["launches"], 1),
                     mfma_units_per_product=units, issued_equiv_TFLOPs=round(units * achieved, 2), issued_equiv_frac=round(units * achieved / PEAK_MFMA_F16, 4),
                     note="achieved / frac count ALGORITHMIC FLOPs; issued_equiv_* = what the matrix pipes execute in fp16-MFMA equivalents",
                     families=fams,
                     all_vocoder_convs=dict(ms=round(voc_ms, 3), mfma_TFLOPs=round(VOC_CONV_FLOP_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e12, 2),
                                            issued_equiv_frac=round(voc_issued / (voc_ms * 1e-3) / 1e12 / PEAK_MFMA_F16, 4),
+                                           hbm_algorithmic_GBps=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9, 1),
+                                           hbm_algorithmic_frac=round(VOC_BYTES_PER_FRAME * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
+                                           hbm_algorithmic_note="SURVEY.md section 8(d)'s numerator in EVERY mode: 2.026 MB per mel frame (layer-wise fp16 contract) / "
+                                                                "time of the generator's conv launches / 8 TB/s -- the figure to hold against north_star's >= 0.40; the "
+                                                                "hbm_contract_* and hbm_pmc_* fields below divide bytes this mode moves, not useful work",
                                            hbm_contract_GBps=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9, 1),
                                            hbm_contract_frac=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
                                            hbm_contract_bytes_per_frame=VOC_BYTES_PER_FRAME_BY_MODE[mode],
                                            hbm_contract_note="this mode's layer-wise byte contract (fp16: 2.026 MB / frame; split precision: fp32 tensors, 2x; "
-                                                             "mx: plane sets + fp32 residual streams, 4.31 MB / frame)"))
+                                                             "mx: plane sets, residuals rebuilt from them, fp32 running MRF sums, 3.55 MB / frame)"))
         if voc_pmc:
             roof["all_vocoder_convs"].update(hbm_pmc_bytes_per_frame=round(voc_pmc, 1), hbm_pmc_GBps=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9, 1),
                                              hbm_pmc_frac=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
@@ -415,6 +465,11 @@ def main():
     ap.add_argument("--sub-batches", type=int, default=0, help="am_vocoder: sub-batches per step (default 1 at N = 1, 8 at N > 1 = configs[3])")
     ap.add_argument("--phonemes", type=int, default=256)
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU baseline (more are slower on the 2 x 64-core box)")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch table of the profiled step to this path (+ .<mode> for the other precisions)")
+    ap.add_argument("--chunk-mb", type=int, default=0, help="ev_config.vocoder_chunk_mb (tuning; 0 = whole tensors)")
+    ap.add_argument("--voc-streams", type=int, default=0, help="ev_config.vocoder_streams (tuning; 0 = engine default)")
+    ap.add_argument("--mx-residual", default="planes", choices=["planes", "fp32"], help="ev_config.mx_residual (A/B: round 3's fp32 residual stream)")
     ap.add_argument("--precision", default="mx", choices=["mx", "fast", "strict"],
                     help="frame-rate path: mx (default, the contract mode: waveform <= 1e-3 on every fixture) = fp32 activations, one fp16 MFMA + "
                          "two block-scaled fp4 MFMAs per product; fast = fp16 MFMA operands / fp16 activations (2.4e-3 on zero-mean audio); "
@@ -473,8 +528,7 @@ def main():
 
     def make_engine(precision, decoder_precision=None):
         e = EVEngine(device_id=local_rank, precision=precision, decoder_precision=decoder_precision,
-                     vocoder_chunk_mb=int(os.environ.get("EV_CHUNK_MB", "0")),       # tuning overrides; 0 = engine default
-                     vocoder_streams=int(os.environ.get("EV_VOC_STREAMS", "0")))
+                     vocoder_chunk_mb=args.chunk_mb, vocoder_streams=args.voc_streams, mx_residual=args.mx_residual)
         e.load_blob_device(blob_t.data_ptr(), blob_t.numel(), keepalive=blob_t)
         return e
 
@@ -488,20 +542,20 @@ def main():
 
     frames, dt = timed(work, args.steps, args.warmup, sync)
     ranks_seen = [0]
+    per_rank = [dict(rank=0, frames=int(frames), s=round(dt, 6))]
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ft = torch.tensor([frames], device=dev, dtype=torch.int64)
-        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
-        frames = int(ft.item())
-        rk = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(rk, torch.tensor([rank], dtype=torch.int64, device=dev))
-        ranks_seen = [int(t.item()) for t in rk]
+        # every rank's own (rank, frames, seconds): a straggler is visible in the line; value = all frames / the slowest rank's time
+        mine = torch.tensor([float(rank), float(frames), dt], device=dev, dtype=torch.float64)
+        allr = [torch.zeros(3, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=int(t[0].item()), frames=int(t[1].item()), s=round(float(t[2].item()), 6)) for t in allr]
+        ranks_seen = [r["rank"] for r in per_rank]
+        frames = sum(r["frames"] for r in per_rank)
+        dt = max(r["s"] for r in per_rank)
 
     roof, stages, kernels, lat, other = None, {}, {}, {}, None
     if rank == 0:
-        roof, stages, kernels = roofline_block(eng, work, torch)
+        roof, stages, kernels = roofline_block(eng, work, torch, args.dump_launches)
         # single-utterance latency (the reference's own call pattern, B = 1; BASELINE configs[0] is 64 phonemes): host-to-host
         # wall time of one ev_synthesize with host inputs, best of 20
         if args.mode == "am_vocoder":
@@ -528,14 +582,16 @@ def main():
                 work2 = Workload(args, eng2, rank, dev, torch, _ffi)
                 n2 = max(3, args.steps // 2)
                 f2, dt2 = timed(work2, n2, 2, lambda: torch.cuda.synchronize())
-                roof2, stages2, _ = roofline_block(eng2, work2, torch)
+                roof2, stages2, _ = roofline_block(eng2, work2, torch, args.dump_launches)
                 other.append(dict(precision=op, waveform_rel_l2_vs_reference=PARITY_LEVEL[op], value=round(f2 / dt2, 1), unit="mel-frames/s",
                                   x_realtime=round(f2 / dt2 * 256 / 16000, 1), ms_per_step=round(dt2 / n2 * 1e3, 3), roofline=roof2,
                                   stage_ms={k: round(v, 3) for k, v in stages2.items()}))
                 eng2.close()
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        # stay in the group until rank 0 has printed the line (it profiles one more step first): a launcher that tears the job down when the first
+        # rank exits must not lose the result, and a rank that died early shows up as a hang / error instead of a short line
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     sr, hop = 16000, 256
@@ -549,16 +605,17 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE_NAME[eng.vocoder_precision], "precision": args.precision, "waveform_rel_l2_vs_reference": PARITY_LEVEL[args.precision],
-        "data": "synthetic", "ranks_seen": ranks_seen, "config": cfg,
+        "data": "synthetic", "ranks_seen": ranks_seen, "ranks": per_rank, "config": cfg,
         "latency": lat, "roofline": roof, "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "kernels_ms": kernels,
         "other_precision": other,
     }
     if world == 1 and args.cpu_utts > 0:
-        line["cpu_baseline"] = cpu_baseline(args.cpu_utts, args.phonemes)
+        line["cpu_baseline"] = cpu_baseline(args.cpu_utts, args.phonemes, args.cpu_threads)
     else:
         line["cpu_baseline"] = None
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVHIP_LIB", os.path.join(_HERE, "csrc", "libevhip.so"))
-EV_ABI_VERSION = 1
+EV_ABI_VERSION = 2
 EV_PREC_F16, EV_PREC_F32, EV_PREC_X3, EV_PREC_MX = 0, 1, 2, 3
 EV_FLAG_DEVICE_INPUTS, EV_FLAG_NO_VOCODER, EV_FLAG_WANT_INT16, EV_FLAG_FORCED_DURATIONS = 1, 2, 4, 8
 
@@ -26,7 +26,8 @@ class ev_config(C.Structure):
         ("rb_kernels", C.c_int32 * 8), ("rb_dils", (C.c_int32 * 4) * 8), ("n_rb_dils", C.c_int32),
         ("sample_rate", C.c_int32), ("decoder_precision", C.c_int32), ("keep_stages", C.c_int32),
         ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("vocoder_streams", C.c_int32),
-        ("vocoder_precision", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("vocoder_precision", C.c_int32), ("mx_residual", C.c_int32), ("decoder_attention", C.c_int32),
+        ("fused_pairs", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -84,6 +85,7 @@ class ev_res_pair_desc(C.Structure):
 _P = C.c_void_p
 SIGNATURES = {
     "ev_default_config": (None, [C.POINTER(ev_config)]),
+    "ev_abi_info": (C.c_int, [C.POINTER(C.c_size_t)]),
     "ev_create": (C.c_int, [C.c_int, C.POINTER(ev_config), C.POINTER(_P)]),
     "ev_destroy": (None, [_P]),
     "ev_last_error": (C.c_char_p, [_P]),
@@ -127,5 +129,12 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        # a stale library (or a stale copy of this file) must fail here, not mis-parse a descriptor later
+        sizes = (C.c_size_t * 4)()
+        ver = l.ev_abi_info(sizes)
+        mine = (C.sizeof(ev_config), C.sizeof(ev_result), C.sizeof(ev_conv_gemm_desc), C.sizeof(ev_res_pair_desc))
+        if ver != EV_ABI_VERSION or tuple(sizes) != mine:
+            raise ImportError(f"{LIB_PATH}: ABI version {ver} / struct sizes {tuple(sizes)} do not match this binding "
+                              f"({EV_ABI_VERSION} / {mine}): rebuild with python emotivoice_amd/csrc/build.py")
         _lib = l
     return _lib

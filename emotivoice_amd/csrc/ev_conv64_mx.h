@@ -393,7 +393,7 @@ static bool conv64_mx_eligible(const ConvGemmParams& p) {
            !p.add16_a && !p.post_lrelu && !p.out32_before_post && !rare_act && (!p.out32 || p.ldo == 64) &&
            (!p.mxo_h || (p.mxo_logC == 6 && p.mxo_q4[0] && p.mxo_q4[1] && p.mxo_qs[0] && p.mxo_qs[1] && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f)) &&
            (!p.res || p.res_dtype == DT_F32 || (p.res_dtype == DT_MX && p.res_x4 && p.res_xs && p.ldres == 64 && p.res_inv_slope >= 1.0f)) &&
-           (!p.acc32 || p.res) && (!p.res || p.act == ACT_NONE) &&
+           (!p.acc32 || p.res) && (!p.res || p.act == ACT_NONE) && (p.res || p.out_scale == 1.0f) &&        // (out_scale lives in the residual branch)
            !(p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f));
 }
 static void launch_conv64_mx(const ConvGemmParams& p, hipStream_t s) {

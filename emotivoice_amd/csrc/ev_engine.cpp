@@ -322,6 +322,8 @@ int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_r
     const double flops = 2.0 * valid_rows * p.N * (double)p.K * p.taps * flop_scale;
     double bytes = valid_rows * ((double)p.K * es + (double)p.N * (p.out16 ? 2 : 0) + (double)p.N * (p.out32 ? 4 : 0)) +
                    (double)p.N * p.K * p.taps * es;
+    // a DT_MX call that launch_conv_gemm will run as the split-precision kernel (no plane-set input, unsupported shape) is recorded as such
+    if (p.dtype == DT_MX && mx_launch_kind(p) == 0) name = strncmp(name, "dec", 3) == 0 ? "dec_f32_gemm" : "voc_conv_gemm_x3";
     KScope ks(h, name, flops, bytes, st, &p);
     launch_conv_gemm(p, st ? st : h->stream);
     return 0;
@@ -409,7 +411,7 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         AttnParams ap{};
         // decoder in the strict / mx modes: split-precision attention (three fp16 MFMAs per product); the token-rate encoder keeps exact fp32
         const bool att_split = prec == DT_F32 && !strcmp(pre, "dec") && (h->cfg.decoder_precision == EV_PREC_X3 || h->cfg.decoder_precision == EV_PREC_MX) &&
-                               C / h->cfg.heads == 48 && !getenv("EV_ATTN_F32");
+                               C / h->cfg.heads == 48 && h->cfg.decoder_attention == 0;
         ap.qkv = qkv.p; ap.dtype = att_split ? (int)DT_F32S : prec; ap.ld = 3 * C; ap.C = C; ap.heads = h->cfg.heads; ap.seq_off = rc.seq_off;
         ap.seq_len = rc.seq_len; ap.B = rc.B; ap.max_len = rc.max_len; ap.out = ctx.p; ap.ldo = C;
         { KScope ks(h, (kn + "_attention").c_str(), 0, 0); launch_attention(ap, h->stream); }
@@ -567,10 +569,9 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         else stage_mx = false;
         // MX stage: the residual stream of a ResBlock exists only as the plane set of lrelu(x, .1) its conv1 reads -- conv2's epilogue rebuilds x from
         // the fp16 hi plane + the fp4 remainder codes (ConvGemmParams::res_x4), so neither the up-conv nor a conv2 inside a ResBlock writes an fp32
-        // copy (tools/precision_study_mx.py: 3.4e-4 -> 4.4e-4; 8.7 instead of 14.1 bytes per element and conv2 launch).  OPT-IN (EV_MX_RESPL=1) until the
-        // generator's parity has been measured with it on the GPU: the kernels' op test passed there, the flow below has not run yet.
-        static const bool rpl_env = getenv("EV_MX_RESPL") != nullptr;
-        const bool rpl = stage_mx && rpl_env;
+        // copy (tools/precision_study_mx.py: 3.4e-4 -> 4.4e-4; 8.7 instead of 14.1 bytes per element and conv2 launch).  Default since round 4 (the
+        // round-3 driver run XPASSed every reference fixture through it); ev_config.mx_residual = 1 restores the separate fp32 residual tensor.
+        const bool rpl = stage_mx && c.mx_residual == 0;
         if (rpl && !keep) p.out32 = nullptr;                   // (kept stages still get the raw up-conv output: the voc_up tap)
         if (gemm(h, p.dtype == DT_MX ? (p.N == 64 && p.K == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx") : gname, p, valid_in, nullptr, 2.0 / 3.0)) return -1;
         const bool next_up_mx = stage_mx && i + 1 < c.n_up && has_mx("voc.up" + std::to_string(i + 1));
@@ -631,10 +632,10 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                 const int dil = c.rb_dils[j][d];
                 const std::string c1 = rb + ".c1." + std::to_string(d), c2 = rb + ".c2." + std::to_string(d);
                 // fused pair kernels: C = 32 (every k) and C = 64 with k = 3 (the HBM-bound end of the generator; fp16 mode only)
-                const bool fused = !x3 && ((cout == 32 && (k == 3 || k == 7 || k == 11)) || (cout == 64 && k == 3)) && !getenv("EV_NO_FUSED_PAIR");
+                const bool fused = !x3 && ((cout == 32 && (k == 3 || k == 7 || k == 11)) || (cout == 64 && k == 3)) && c.fused_pairs == 0;
                 // EV_PREC_MX at C = 32: the whole pair in one persistent kernel (ev_pair_mx.h), x fp32 in, fp32 out
-                const bool fused_mx = mx && cout == 32 && (k == 3 || k == 7 || k == 11) && has_wt(c1 + ".wpmx") && has_wt(c2 + ".wpmx") &&
-                                      !getenv("EV_NO_FUSED_PAIR");
+                const bool fused_mx = mx && cout == 32 && (k == 3 || k == 7 || k == 11) && (k - 1) * (dil + 1) <= 64 && has_wt(c1 + ".wpmx") && has_wt(c2 + ".wpmx") &&
+                                      c.fused_pairs == 0;
                 // the plane set of lrelu(x, .1) this pair starts from: conv1's operand and, with rpl, conv2's residual
                 const PlaneBuf& xin = d == 0 ? vb.pl_xu : ((d - 1) % 2 == 0 ? vb.pl_a : vb.pl_b);
                 if (fused_mx) {
@@ -650,17 +651,17 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                 } else if (!fused) {
                     // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
                     p = gemm_defaults();
-                    if (voc_weights(h, c1, x3, p, mx && cout == 64)) return -1;
+                    if (voc_weights(h, c1, x3, p, false)) return -1;      // (no plane-set input here: DT_MX would only fall back to the split kernel)
                     p.A = xcur; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
                     p.taps = k; p.dil = dil; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
                     p.pro_lrelu = 1; p.pro_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f; p.ldo = cout;
                     set_out(p, vb.tmp[bj].p);
                     const int e1 = (2 * (c.n_rb_dils - 1 - d) + 1) * 256, lo1 = std::max(0, a0 - e1), hi1 = std::min(rows_out, b0 + e1);
-                    if (gemm(h, p.dtype == DT_MX ? "voc_conv_c64_mx" : gname, sub(p, lo1, hi1), valid_out * frac, sj)) return -1;
+                    if (gemm(h, gname, sub(p, lo1, hi1), valid_out * frac, sj)) return -1;
                 }
                 // x = c2(xt) + x  (models.py:54-56)
                 p = gemm_defaults();
-                if (voc_weights(h, c2, x3, p, stage_mx || (mx && cout == 64))) return -1;
+                if (voc_weights(h, c2, x3, p, stage_mx)) return -1;
                 p.A = vb.tmp[bj].p; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
                 if (stage_mx) {
                     if (p.dtype != DT_MX) return fail(h, "MX stage: %s has no fp4 planes", c2.c_str());
@@ -693,7 +694,10 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                         else p.out32 = (float*)vb.mrf32.p;
                     } else if (x3) {
                         p.out32 = (float*)vb.nxt[i].p;               // raw MRF mean (= the voc_mrf tap); consumers apply the leaky-relu
-                        if (next_up_mx) mx_out(p, mx_view(vb.pl_nxt, (size_t)rows_out, cout), 0.1f);      // ... or read these planes (models.py:118)
+                        if (next_up_mx) {
+                            mx_out(p, mx_view(vb.pl_nxt, (size_t)rows_out, cout), 0.1f);      // ... or read these planes (models.py:118)
+                            if (rpl && !keep) p.out32 = nullptr;                              // the next up-conv reads only the planes: no fp32 copy of the stage output
+                        }
                     } else {
                         p.post_lrelu = 1; p.post_slope = last_stage ? 0.01f : 0.1f;   // models.py:118 / :127
                         p.out16 = vb.nxt[i].p;
@@ -878,6 +882,11 @@ void ev_default_config(ev_config* c) {
     c->sample_rate = 16000; c->decoder_precision = EV_PREC_F16; c->keep_stages = 0; c->token_rate_split = 1;
 }
 
+int ev_abi_info(size_t sizes[4]) {
+    if (sizes) { sizes[0] = sizeof(ev_config); sizes[1] = sizeof(ev_result); sizes[2] = sizeof(ev_conv_gemm_desc); sizes[3] = sizeof(ev_res_pair_desc); }
+    return EV_ABI_VERSION;
+}
+
 const char* ev_last_error(ev_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
@@ -916,6 +925,8 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
         return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
     if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3 && cfg->vocoder_precision != EV_PREC_MX)
         return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16, EV_PREC_X3 or EV_PREC_MX");
+    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs) & ~1)
+        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs must be 0 or 1");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));
@@ -1536,6 +1547,7 @@ int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* stream) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int ev_op_resblock_pair_c32_mx(const ev_res_pair_desc* d, void* stream) {
+    static_assert(sizeof(ev_res_pair_desc) == sizeof(ResPairParams), "descriptor layout must match ResPairParams");
     ResPairParams p;
     memcpy(&p, d, sizeof p);
     if (p.M <= 0 || p.dil < 1 || (p.k - 1) * p.dil > 64) return -2;

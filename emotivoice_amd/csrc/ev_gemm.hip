@@ -813,7 +813,7 @@ static void launch_epi(const ConvGemmParams& p, hipStream_t s) {
 
 // which straight-line epilogue instantiation a fp16 launch asks for (EPI_GENERIC: none)
 static int fp16_epi_variant(const ConvGemmParams& p) {
-    static const bool force_generic = getenv("EV_EPI_GENERIC") != nullptr;     // A/B switch for tools/bench_gemm.py
+    static const bool force_generic = tuning_env("EV_EPI_GENERIC") != nullptr;     // A/B switch for tools/bench_gemm.py
     const bool odd_slope = (p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f)) ||
                            (p.post_lrelu && !(p.post_slope >= 0.f && p.post_slope <= 1.f));     // max(v, s v) form needs s in [0, 1]
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
@@ -1221,15 +1221,15 @@ static void launch_dt(const ConvGemmParams& p_in, hipStream_t s) {
     // 998 -> 1039 TF/s), +1-4 % on the up-convs and decoder GEMMs, nothing at C = 128 / k >= 7 and -1...-4 % on the HBM-bound
     // C = 128 / k = 3 layers (tools/bench_gemm.py --dbg 0,1,0,1, profiles/r2_e_gemm_setprio.txt): on for N >= 256 only.
     ConvGemmParams p = p_in;
-    static const char* prio_env = getenv("EV_GEMM_PRIO");            // "0" / "1": A/B override
+    static const char* prio_env = tuning_env("EV_GEMM_PRIO");            // "0" / "1": A/B override
     if (prio_env ? prio_env[0] == '1' : p.N >= 256) p.reserved0 |= 1;
     if (p.N % 128 == 0) {
         // 256-row tiles halve the weight-tile traffic per FLOP and the barrier count per MFMA; since the epilogue stopped scaling
         // with vmcnt round trips they win on every shape measured (tools/bench_gemm.py, EV_GEMM_TILE=128/256), so 128-row
         // tiles are only used to fill the 256 CUs when there are few tiles.  The fp32 kernel is MFMA-rate bound (1/16 of fp16),
         // weight traffic is irrelevant there, so it only takes the big tile when there are plenty of them.
-        static const char* force = getenv("EV_GEMM_TILE");            // "128" / "256": A/B switch for tools/bench_gemm.py
-        static const char* smallm = getenv("EV_GEMM_SMALLM");         // "0" / "1": A/B switch for the latency configuration below
+        static const char* force = tuning_env("EV_GEMM_TILE");            // "128" / "256": A/B switch for tools/bench_gemm.py
+        static const char* smallm = tuning_env("EV_GEMM_SMALLM");         // "0" / "1": A/B switch for the latency configuration below
         const long tiles256 = (long)(p.M / 256) * (p.N / 128);
         // Latency configuration (single utterances: B = 1 is the reference's own call pattern): with a handful of 128-wide tiles most
         // CUs idle while each tile walks its whole (K-chunk, tap) sequence -- 88 steps = ~70 us for one C = 256 / k = 11 conv of a
@@ -1239,7 +1239,7 @@ static void launch_dt(const ConvGemmParams& p_in, hipStream_t s) {
         if (latency_cfg && !force) return launch_cfg<TIn, 256, 32, 4, 1>(p, s);
         if constexpr (sizeof(TIn) == 2) {
             // phased 8-wave kernel for the shapes that fill the chip with 256 x 128 tiles (bit-identical results, see its header)
-            static const char* ph_env = getenv("EV_GEMM_PHASED");       // "0" / "1": A/B switch
+            static const char* ph_env = tuning_env("EV_GEMM_PHASED");       // "0" / "1": A/B switch
             const bool ph_on = (ph_env ? ph_env[0] == '1' : true) && !(p.reserved0 & 4);      // reserved0 bit 2: in-process A/B (tools/bench_gemm.py --dbg)
             if (ph_on && !force && tiles256 >= 256 && launch_phased(p, fp16_epi_variant(p), s)) return;
         }
@@ -1249,7 +1249,7 @@ static void launch_dt(const ConvGemmParams& p_in, hipStream_t s) {
         else launch_cfg<TIn, 128, 128, 2, 2>(p, s);
     } else if (p.N % 64 == 0) {
         if constexpr (sizeof(TIn) == 2) {          // C = 64 stage, 7 / 11 taps: phased kernel with two taps per step
-            static const char* ph_env = getenv("EV_GEMM_PHASED");
+            static const char* ph_env = tuning_env("EV_GEMM_PHASED");
             const bool ph_on = (ph_env ? ph_env[0] == '1' : true) && !(p.reserved0 & 4);
             if (ph_on && (long)(p.M / 256) * (p.N / 64) >= 512 && launch_phased(p, fp16_epi_variant(p), s)) return;
         }
@@ -1674,8 +1674,8 @@ static void launch_split_epi(const ConvGemmParams& p, hipStream_t s) {
 static void launch_split(const ConvGemmParams& p, hipStream_t s) {
     // split-precision GEMMs write fp32 only: plain / leaky-relu / fp32 residual (+ fp32 accumulate-in) / relu-gelu (exact erff:
     // fp32 output) use the straight-line epilogue, the per-utterance bias of embed_projection1 (and anything else) the generic one
-    static const bool old_kernel = getenv("EV_X3_OLD") != nullptr;       // A/B switch: first-generation 128 x 64 kernel
-    static const bool force_generic = getenv("EV_EPI_GENERIC") != nullptr;
+    static const bool old_kernel = tuning_env("EV_X3_OLD") != nullptr;       // A/B switch: first-generation 128 x 64 kernel
+    static const bool force_generic = tuning_env("EV_EPI_GENERIC") != nullptr;
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
     const bool odd_slope = p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f);       // max(v, s v) form needs s in [0, 1]
     const bool o32 = p.out32 && !p.out16 && !p.out32_before_post && !p.post_lrelu;
@@ -2051,7 +2051,7 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s) {
     const int h2 = (p.k - 1) / 2, bmo = 256 - 2 * h2;
     const int ntiles = (p.M + bmo - 1) / bmo;
     const int grid = ntiles < n_cu ? ntiles : n_cu;
-    static const char* one_env = getenv("EV_PAIR_1B");                   // "1": one block per CU for every k (A/B switch)
+    static const char* one_env = tuning_env("EV_PAIR_1B");                   // "1": one block per CU for every k (A/B switch)
     const bool twob = p.k <= 3 && !(one_env && one_env[0] == '1') && !(p.epi.reserved0 & 4) && ntiles >= 4 * n_cu;     // (reserved0 bit 2: in-process A/B)
     const size_t lds = pair_lds_bytes(p.k, twob);
     const int grid2 = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
@@ -2391,6 +2391,11 @@ void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s) {
     if (p.epi.add16_a) hipLaunchKernelGGL((resblock_pair_c64_kernel<3, 2>), dim3(grid), dim3(512), bytes, s, p);
     else if (p.epi.acc32) hipLaunchKernelGGL((resblock_pair_c64_kernel<3, 1>), dim3(grid), dim3(512), bytes, s, p);
     else hipLaunchKernelGGL((resblock_pair_c64_kernel<3, 0>), dim3(grid), dim3(512), bytes, s, p);
+}
+
+int mx_launch_kind(const ConvGemmParams& p) {
+    if (p.dtype != DT_MX) return 0;
+    return conv64_mx_eligible(p) ? 2 : (mx_eligible(p) ? 1 : 0);
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {

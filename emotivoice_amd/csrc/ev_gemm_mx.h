@@ -191,6 +191,18 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const int ws_off = MX_WS_OFF + wc * TC + fr;                       // + tap * 128 + a * 16
     const int xs_off = MX_XS_OFF + (wt * 64 + fr + soff) * 4 + fq;     // + (tap * dil + b * 16) * 4
 
+    // A tile without a single valid row (the gap rows between utterances and the padding behind the last one are whole 256-row tiles at the generator's
+    // upsampled rates: 64 of the 8256 tiles of a stage-1 launch at B = 32 x 1024 frames, exactly the ones that spill 16 full rounds of 512 resident
+    // blocks into a 17th) needs no products: its outputs are the epilogue's masked zeros whatever the accumulators hold, so it goes straight there.
+    // Every wave reads the tile's 256 validity bytes itself (4 rows per lane) -- wave-uniform and identical in all 8 waves, no barrier involved.
+    bool tile_live = true;
+    if (p.row_valid) {
+        const uint8_t* vp = p.row_valid;
+        const int r4 = m0 + lane * 4, vs = p.valid_shift;
+        const unsigned any = vp[r4 >> vs] | vp[(r4 + 1) >> vs] | vp[(r4 + 2) >> vs] | vp[(r4 + 3) >> vs];
+        tile_live = __builtin_amdgcn_ballot_w64(any != 0) != 0ull;
+    }
+    if (tile_live) {
     EV_MX_ISSUE_X(xb16, sc0, 2u, false, 0, 0)
     EV_MX_ISSUE_X(xb16, sc0, 2u, false, 0, 1)
     EV_MX_ISSUE_X(xb16, sc0, 2u, false, 0, 2)
@@ -301,8 +313,9 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wc == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+    }       // tile_live
 #ifdef EV_MX_ABL
-    if (abl & 2) {
+    if ((p.reserved0 >> 4) & 2) {
         if (p.M < 0) {          // never: keeps the accumulators alive
             float sum = 0.f;
 #pragma unroll
@@ -342,7 +355,8 @@ static int mx_epi_variant(const ConvGemmParams& p) {
     const int m = mxp ? EPI_MXP : 0;
     if (respl) {
         if (!(p.res_x4 && p.res_xs && p.ldres == p.N && p.res_inv_slope >= 1.0f)) return -1;
-        if (!p.out32) return (mxp && !p.acc32) ? (EPI_RESPL | EPI_LEAN | EPI_MXP) : -1;          // conv2 of a pair inside a ResBlock: planes only
+        // planes only: conv2 of a pair inside a ResBlock; with the running MRF sum added: the last conv of a stage whose fp32 value only the next up-conv's planes carry
+        if (!p.out32) return mxp ? (p.acc32 ? (EPI_RESPL | EPI_ACC32 | EPI_LEAN | EPI_MXP) : (EPI_RESPL | EPI_LEAN | EPI_MXP)) : -1;
         return p.acc32 ? (EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | m) : (EPI_RESPL | EPI_O32 | EPI_LEAN | m);
     }
     if (p.res && !res32) return mxp ? -1 : EPI_GENERIC;
@@ -355,7 +369,7 @@ static int mx_epi_variant(const ConvGemmParams& p) {
 #define EV_MX_VARIANTS(X) X(EPI_O32) X(EPI_RES32 | EPI_O32 | EPI_LEAN) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_MXP) X(EPI_O32 | EPI_MXP) \
     X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RARE_ACT | EPI_MXP) X(EPI_GENERIC)   \
     X(EPI_RESPL | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_O32 | EPI_LEAN | EPI_MXP)                                    \
-    X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP)
+    X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_ACC32 | EPI_LEAN | EPI_MXP)
 template <int TAPS>
 static void launch_mx_taps(const ConvGemmParams& p, int e, hipStream_t s) {
     switch (e) {

@@ -4,8 +4,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace ev {
+
+// A/B switches of the kernel launchers (EV_GEMM_TILE, EV_ATTN_X3_NW, ...: tools/bench_*.py) exist only in tuning builds
+// (`build.py --variant tune EV_TUNING`, loaded through EVHIP_LIB): the product library reads no environment variable; what an
+// integrator may choose is an ev_config field.
+#ifdef EV_TUNING
+inline const char* tuning_env(const char* name) { return getenv(name); }
+#else
+inline const char* tuning_env(const char*) { return nullptr; }
+#endif
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LRELU = 3, ACT_TANH = 4 };
 enum DType { DT_F16 = 0, DT_F32 = 1, DT_F32S = 2, DT_MX = 3 };   // F32S: fp32 activations, fp16 hi/lo split weights (ConvGemmParams::W / W_lo)
@@ -62,6 +72,9 @@ size_t mx_scratch_bytes(int M, int K);
 // 0 if the plane-set fields of a call are consistent with its dtype, shape and epilogue (launch_conv_gemm would run it)
 int mx_check(const ConvGemmParams& p);
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
+// which kernel launch_conv_gemm runs a DT_MX call on: 0 = the split-precision fallback (three fp16 MFMAs per product), 1 = conv_gemm_mx_kernel,
+// 2 = conv_c64_mx_kernel (profiling records name the launch by this, not by what the caller hoped for)
+int mx_launch_kind(const ConvGemmParams& p);
 // per-device setup of the kernels in ev_gemm.hip (large-LDS opt-in, CU count of the persistent kernels); 0 = OK
 int init_device_kernels(int device);
 

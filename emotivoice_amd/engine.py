@@ -34,7 +34,8 @@ def resolve_precision(precision, decoder_precision, vocoder_precision):
 
 def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages: bool = False,
                    token_rate: str = "split", vocoder_chunk_mb: int = 0, vocoder_streams: int = 0,
-                   vocoder_precision: str = "f16") -> _ffi.ev_config:
+                   vocoder_precision: str = "f16", mx_residual: str = "planes", decoder_attention: str = "split",
+                   fused_pairs: bool = True) -> _ffi.ev_config:
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
     for f in ("n_vocab", "n_speaker", "n_mels", "hidden", "heads", "enc_layers", "dec_layers", "ffn_kernel", "bert_dim",
@@ -58,6 +59,10 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages
     cfg.vocoder_chunk_mb = int(vocoder_chunk_mb)
     cfg.vocoder_streams = int(vocoder_streams)
     cfg.token_rate_split = {"split": 1, "f32": 0}[token_rate]
+    # engine switches (ev_config; they were environment variables until round 3)
+    cfg.mx_residual = {"planes": 0, "fp32": 1}[mx_residual]
+    cfg.decoder_attention = {"split": 0, "f32": 1}[decoder_attention]
+    cfg.fused_pairs = 0 if fused_pairs else 1
     return cfg
 
 
@@ -66,14 +71,15 @@ class EVEngine:
 
     def __init__(self, shapes: Optional[EVShapes] = None, device_id: int = 0, decoder_precision: Optional[str] = None,
                  keep_stages: bool = False, token_rate: str = "split", vocoder_chunk_mb: int = 0,
-                 vocoder_streams: int = 0, vocoder_precision: Optional[str] = None, precision: Optional[str] = None):
+                 vocoder_streams: int = 0, vocoder_precision: Optional[str] = None, precision: Optional[str] = None,
+                 mx_residual: str = "planes", decoder_attention: str = "split", fused_pairs: bool = True):
         self.shapes = shapes or EVShapes()
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
         decoder_precision, vocoder_precision = resolve_precision(precision, decoder_precision, vocoder_precision)
         self.decoder_precision, self.vocoder_precision = decoder_precision, vocoder_precision
         cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate, vocoder_chunk_mb, vocoder_streams,
-                             vocoder_precision)
+                             vocoder_precision, mx_residual, decoder_attention, fused_pairs)
         if self._lib.ev_create(device_id, C.byref(cfg), C.byref(self._h)) != 0:
             raise EVError(self._lib.ev_last_error(None).decode())
         self.device_id = device_id

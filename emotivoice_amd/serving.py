@@ -55,6 +55,7 @@ class DynamicBatcher:
         self._carry: List[SynthesisRequest] = []
         self.batches: List[int] = []          # sizes of the batches formed so far (observability / tests)
         self.retried: int = 0                 # batches that failed as a whole and were re-run one request at a time
+        self.loop_errors: int = 0             # exceptions the worker loop itself swallowed to stay alive (should stay 0)
         self._stop = False
         self._lock = threading.Lock()         # orders submit's (closed? -> enqueue) against close's (closed := True -> sentinel)
         self._thread = threading.Thread(target=self._loop, name="ev-batcher", daemon=True)
@@ -97,8 +98,13 @@ class DynamicBatcher:
                 self._stop = True
                 self._q.put(None)
         self._thread.join(timeout=timeout)
-        # whatever is still queued or carried (worker timed out, or died) must not leave its client waiting
-        left = list(self._carry) if not self._thread.is_alive() else []
+        if self._thread.is_alive():
+            # the worker is still inside a batch (join timed out): it owns the queue and _carry; the sentinel stays queued, so it exits after
+            # draining what it has, and nothing is taken from under it here
+            return
+        # the worker has exited (or died): whatever is still queued or carried must not leave its client waiting
+        left = list(self._carry)
+        self._carry = []
         while True:
             try:
                 r = self._q.get_nowait()
@@ -107,8 +113,7 @@ class DynamicBatcher:
             if r is not None:
                 left.append(r)
         for r in left:
-            if not r.future.done():
-                r.future.set_exception(RuntimeError("batcher closed"))
+            _resolve(r.future, exception=RuntimeError("batcher closed"))
 
     def _take_batch(self) -> List[SynthesisRequest]:
         """Block for the first request, then keep collecting until the batch is full, the token budget is reached or
@@ -157,31 +162,52 @@ class DynamicBatcher:
         if len(wavs) != len(batch):
             raise RuntimeError("synth_fn returned %d waveforms for %d requests" % (len(wavs), len(batch)))
         for r, w in zip(batch, wavs):
-            r.future.set_result(np.array(w, np.float32, copy=True))
+            _resolve(r.future, result=np.array(w, np.float32, copy=True))
 
     def _loop(self):
         while True:
-            batch = self._take_batch()
-            if not batch:
-                if self._stop and not self._carry:
-                    return
-                continue
-            self.batches.append(len(batch))
             try:
-                self._run(batch)
-            except Exception as e:
-                if len(batch) == 1:
-                    batch[0].future.set_exception(e)
+                batch = self._take_batch()
+                if not batch:
+                    if self._stop and not self._carry:
+                        return
                     continue
-                # a batch failed as a whole: re-run its requests one at a time so that only the offender fails
-                self.retried += 1
-                for r in batch:
-                    if r.future.done():
+                # a client may cancel its Future while it waits: such requests are dropped here, and a Future that is cancelled
+                # later (mid-batch) is simply not resolved (_resolve) -- neither may take the worker thread down
+                batch = [r for r in batch if r.future.set_running_or_notify_cancel()]
+                if not batch:
+                    continue
+                self.batches.append(len(batch))
+                try:
+                    self._run(batch)
+                except Exception as e:
+                    if len(batch) == 1:
+                        _resolve(batch[0].future, exception=e)
                         continue
-                    try:
-                        self._run([r])
-                    except Exception as e1:
-                        r.future.set_exception(e1)
+                    # a batch failed as a whole: re-run its requests one at a time so that only the offender fails
+                    self.retried += 1
+                    for r in batch:
+                        if r.future.done():
+                            continue
+                        try:
+                            self._run([r])
+                        except Exception as e1:
+                            _resolve(r.future, exception=e1)
+            except Exception:          # nothing a single request does may end the thread every later request depends on
+                self.loop_errors += 1
+
+
+def _resolve(future: Future, result=None, exception: Optional[BaseException] = None):
+    """set_result / set_exception that tolerates a Future its client has cancelled or that was resolved already."""
+    try:
+        if future.done():
+            return
+        if exception is not None:
+            future.set_exception(exception)
+        else:
+            future.set_result(result)
+    except Exception:            # concurrent.futures.InvalidStateError (cancelled between the check and the set)
+        pass
 
 
 def engine_synth_fn(engine) -> Callable[[List[dict], float], Sequence[np.ndarray]]:

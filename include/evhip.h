@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 1
+#define EV_ABI_VERSION 2      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info */
 
 typedef struct ev_handle ev_handle;
 
@@ -79,7 +79,16 @@ typedef struct ev_config {
                                    EV_PREC_MX: the X3 data flow, but layers with >= 128 channels evaluate a product as ONE fp16 MFMA
                                    (hi x hi) + two block-scaled fp4 MFMAs for the cross terms (v_mfma_scale_f32_16x16x128_f8f6f4) on
                                    operand planes written by the producing layer: waveform within ~4e-4 of the reference */
-    int32_t reserved[4];
+    /* engine switches that used to be environment variables (read per layer per forward); all default to 0 */
+    int32_t mx_residual;        /* EV_PREC_MX generator: 0 (default) = the residual stream of a ResBlock travels ONLY as the plane set its
+                                   conv1 reads (fp16 hi plane + fp4 remainder codes; conv2's epilogue rebuilds x from it: 8.7 instead of
+                                   14.1 bytes per element and conv2 launch, worst fixture 5.3e-4 instead of 4.4e-4); 1 = a separate fp32
+                                   residual tensor beside the planes (round 3's flow) */
+    int32_t decoder_attention;  /* decoder self-attention in the X3 / MX modes: 0 (default) = split precision (three fp16 MFMAs per
+                                   product, K / V tiles staged through LDS); 1 = exact fp32 MFMA kernel (the token-rate encoder's) */
+    int32_t fused_pairs;        /* 0 (default) = fused ResBlock-pair kernels where they exist (C = 32 every k, C = 64 / k = 3 in fp16); 1 = every
+                                   conv as its own launch (A/B switch, bit-identical in the fp16 mode) */
+    int32_t reserved[1];
 } ev_config;
 
 /* Precision of the frame-rate path.  F16: fp16 MFMA operands (what BASELINE.json's bf16 / fp16 configs name).
@@ -118,6 +127,11 @@ typedef struct ev_result {
 } ev_result;
 
 void ev_default_config(ev_config* cfg);
+
+/* What the loaded library was built as: EV_ABI_VERSION and the sizes of the structs a binding mirrors (ev_config, ev_result, and the two
+ * descriptors of include/evhip_ops.h), so that a stale binding or a stale libevhip.so is an error at load time instead of a mis-parsed struct.
+ * sizes: 4 entries {sizeof(ev_config), sizeof(ev_result), sizeof(ev_conv_gemm_desc), sizeof(ev_res_pair_desc)}; returns EV_ABI_VERSION. */
+int ev_abi_info(size_t sizes[4]);
 
 int ev_create(int device_id, const ev_config* cfg, ev_handle** out);
 void ev_destroy(ev_handle* h);

@@ -984,7 +984,7 @@ def _host_plane_set(a):
 
 @pytest.mark.parametrize("Cc,k,dil,mode", [(128, 3, 1, "planes"), (128, 7, 3, "o32"), (128, 11, 1, "o32+planes"), (256, 3, 5, "acc"),
                                            (256, 7, 1, "acc+planes"), (64, 3, 1, "planes"), (64, 7, 3, "o32+planes"), (64, 11, 5, "acc+planes"),
-                                           (64, 3, 5, "acc")])
+                                           (64, 3, 5, "acc"), (128, 7, 1, "acc>planes"), (256, 3, 3, "acc>planes"), (64, 7, 1, "acc>planes")])
 def test_mx_residual_from_planes(lib, Cc, k, dil, mode):
     """res_dtype 3: conv2 of a ResBlock pair takes its residual from the plane set of lrelu(x, 0.1) that conv1 read -- x' = lrelu^-1(hi + Q4(lo)) --
     instead of an fp32 tensor (conv_gemm_mx_kernel's EPI_RESPL epilogues at C = 128 / 256, conv_c64_mx_kernel<K, MODE, true> at C = 64).
@@ -1022,7 +1022,8 @@ def test_mx_residual_from_planes(lib, Cc, k, dil, mode):
     t64 = lambda z: torch.from_numpy(np.asarray(z, np.float64))          # noqa: E731
     d_hi, d_lo, d_mx = torch.from_numpy(hi).cuda(), torch.from_numpy(lo16).cuda(), torch.from_numpy(planes).cuda()
     acc = torch.randn(M, Cc, device="cuda")
-    want32, planes_out, acc_in = mode != "planes", "planes" in mode, mode.startswith("acc")
+    # ("acc>planes": the last conv of a stage in the engine's default flow -- running MRF sum in, ONLY the next up-conv's planes out)
+    want32, planes_out, acc_in = mode not in ("planes", "acc>planes"), "planes" in mode, mode.startswith("acc")
     out = torch.full((M, Cc), 7.0, device="cuda")
     ps_o = _PlaneSet(M, Cc)
     d = _ffi.ev_conv_gemm_desc()

@@ -143,6 +143,70 @@ def test_close_resolves_every_pending_future():
         b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
 
 
+def test_cancelled_future_does_not_kill_the_worker():
+    """a client cancelling its Future while its batch runs made set_result raise InvalidStateError, the error path raised
+    again on the same Future and the batcher thread died -- every later request hung."""
+    import threading
+    started, gate = threading.Event(), threading.Event()
+
+    def slow(utts, alpha):
+        started.set()
+        gate.wait(5)
+        return [np.full(4, len(u["ling"]), np.float32) for u in utts]
+
+    b = DynamicBatcher(slow, max_batch=1, max_wait_ms=1)
+    f1 = b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
+    assert started.wait(5)
+    f2 = b.submit(np.arange(5), 0, np.zeros(768), np.zeros(768))
+    assert f2.cancel()                      # still queued: dropped when its batch is formed
+    f1.cancel()                             # running: cancel() is refused, but the Future API allows the call
+    gate.set()
+    f3 = b.submit(np.arange(7), 0, np.zeros(768), np.zeros(768))
+    assert f3.result(timeout=5)[0] == 7     # the worker is alive and serving
+    assert f1.result(timeout=5)[0] == 3
+    assert b._thread.is_alive() and b.loop_errors == 0
+    b.close()
+
+
+def test_worker_survives_a_future_resolved_behind_its_back():
+    """A Future that is already resolved (e.g. failed by the caller's timeout handling) when the batch finishes must be skipped, and an
+    exception from synth_fn on such a request must not end the thread either."""
+    def boom(utts, alpha):
+        raise RuntimeError("synth failed")
+
+    b = DynamicBatcher(boom, max_batch=1, max_wait_ms=1)
+    f = b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
+    with pytest.raises(RuntimeError, match="synth failed"):
+        f.result(timeout=5)
+    g = b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
+    with pytest.raises(RuntimeError, match="synth failed"):
+        g.result(timeout=5)
+    assert b._thread.is_alive()
+    b.close()
+
+
+def test_close_with_a_busy_worker_leaves_it_its_sentinel():
+    """close() whose join timed out used to drain the queue -- sentinel included -- so the worker blocked forever after its
+    batch and its carried requests were never failed.  Now a live worker keeps the queue: it finishes, sees the sentinel and exits."""
+    import threading
+    gate = threading.Event()
+
+    def slow(utts, alpha):
+        gate.wait(5)
+        return [np.zeros(4, np.float32) for _ in utts]
+
+    b = DynamicBatcher(slow, max_batch=1, max_wait_ms=1)
+    futs = [b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768), alpha=1.0 + i) for i in range(3)]
+    b.close(timeout=0.05)                   # the worker is inside the first batch: join times out
+    assert b._thread.is_alive()
+    gate.set()
+    b._thread.join(5)
+    assert not b._thread.is_alive()         # it drained its requests, met the sentinel and returned
+    for f in futs:
+        assert f.done()
+    b.close()                               # idempotent
+
+
 def test_token_budget_splits_batches():
     log = []
     b = DynamicBatcher(_fake_synth(log, 0.0), max_batch=64, max_wait_ms=50, max_tokens=100)

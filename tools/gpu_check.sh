@@ -6,12 +6,13 @@ mkdir -p gpurun_out
 STAGES="${@:-ops parity smoke bench}"
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > gpurun_out/device.log
 nproc >> gpurun_out/device.log
+python -c "import bench; print(bench.csrc_hash())" > gpurun_out/csrc_hash.txt      # what every measurement of this call ran on (profile_summary.py stamps it)
 for st in $STAGES; do
   case $st in
     ops)    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 600 > gpurun_out/ops.log 2>&1; echo "ops rc=$?";;
     parity) timeout 1800 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 900 > gpurun_out/parity.log 2>&1; echo "parity rc=$?";;
     smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?";;
-    bench)  EV_DUMP_LAUNCHES=gpurun_out/launches.json timeout 900 python bench.py --steps 10 --warmup 3 --cpu-utts 4 > gpurun_out/bench.log 2>&1; echo "bench rc=$?";;
+    bench)  timeout 900 python bench.py --steps 10 --warmup 3 --cpu-utts 4 --dump-launches gpurun_out/launches.json > gpurun_out/bench.log 2>&1; echo "bench rc=$?";;
     gen)    timeout 900 python -m pytest tests/test_gpu_generator.py tests/test_gpu_api.py tests/test_gpu_simbert.py tests/test_gpu_dist.py -m gpu -q --timeout 600 > gpurun_out/gen.log 2>&1; echo "gen rc=$?";;
     pmc)    cd /tmp && export TMPDIR=/tmp
             timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_fetch" -o f -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --cpu-utts 0 --no-other-precision > "$GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log" 2>&1
@@ -30,7 +31,7 @@ for st in $STAGES; do
             timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_cal_write" -o c -- python "$GRAFT_REPO_ROOT/tools/pmc_calibrate.py" > "$GRAFT_REPO_ROOT/gpurun_out/pmc_cal_write.log" 2>&1
             echo "pmccal rc=$?"; cd "$GRAFT_REPO_ROOT";;
     dist2)  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --force-device 0 --batch 8 > gpurun_out/dist2.log 2>&1; echo "dist2 rc=$?"; tail -n 3 gpurun_out/dist2.log | cut -c1-600;;
-    prof)   cd /tmp && export TMPDIR=/tmp && EV_VOC_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --cpu-utts 0 --no-other-precision > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$GRAFT_REPO_ROOT";;
+    prof)   cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --cpu-utts 0 --no-other-precision --voc-streams 1 > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$GRAFT_REPO_ROOT";;
   esac
 done
 tail -n 30 gpurun_out/ops.log gpurun_out/parity.log gpurun_out/gen.log gpurun_out/smoke.log gpurun_out/bench.log 2>/dev/null | tail -n 120

@@ -160,14 +160,16 @@ def main():
             "hbm_bytes_per_launch": fam.get(dom, {}).get("hbm_bytes_per_launch"),
             "rocprof_avg_launch_ms_per_forward": avgs, "mode": args.mode, "dominant_family": dom,
         }
-        json.dump(doc, open(os.path.join(pdir, args.tag + "_hbm_traffic.json"), "w"), indent=1)
         # latest_hbm_traffic.json: one entry per precision mode (bench.py reads roofline.traffic of its mode from it)
         lp = os.path.join(pdir, "latest_hbm_traffic.json")
         latest = json.load(open(lp)) if os.path.exists(lp) else {}
         if "families" in latest and "f16" not in latest:          # round-2 layout: the whole file was the fp16 measurement
             latest = {"f16": latest}
         latest[args.mode] = doc
+        hp = os.path.join(OUT, "csrc_hash.txt")          # written on the GPU box by tools/gpu_check.sh: the kernel sources the passes ran on
+        latest["csrc_hash"] = doc["csrc_hash"] = open(hp).read().strip() if os.path.exists(hp) else None
         json.dump(latest, open(lp, "w"), indent=1)
+        json.dump(doc, open(os.path.join(pdir, args.tag + "_hbm_traffic.json"), "w"), indent=1)
         print(json.dumps({k: v for k, v in doc.items() if k not in ("families",)}, indent=1))
     sq = {}
     ps = find_csv("pmc_sq", "counter_collection.csv")

@@ -3,7 +3,7 @@ timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x --timeout 300 -k
 tail -n 5 gpurun_out/ops_mx.log
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 600 -k "(mx or strict) and (golden or taps or batch_invariance or shortest)" > gpurun_out/parity_mx.log 2>&1; echo "parity_mx rc=$?"
 tail -n 30 gpurun_out/parity_mx.log
-EV_DUMP_LAUNCHES=gpurun_out/launches_mx.json timeout 600 python bench.py --steps 5 --warmup 2 --cpu-utts 0 --precision mx --no-other-precision > gpurun_out/bench_mx.log 2>&1; echo "bench_mx rc=$?"
+timeout 600 python bench.py --steps 5 --warmup 2 --cpu-utts 0 --precision mx --no-other-precision --dump-launches gpurun_out/launches_mx.json > gpurun_out/bench_mx.log 2>&1; echo "bench_mx rc=$?"
 python - <<'PY'
 import json
 l=[x for x in open("gpurun_out/bench_mx.log") if x.startswith("{")]
