@@ -367,6 +367,331 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
 #undef EV_C64_OK
 }
 
+
+// ---- Round 4: the same conv with the block's eight waves split into TWO GROUPS one barrier apart (the phased conv-GEMM kernel's schedule applied to
+// the persistent kernel).  conv_c64_mx_kernel runs its eight waves in lock-step: [requests] [MFMAs] barrier [slab -> LDS] [epilogue] barrier, and an item
+// costs the SUM of the phases (per 256-row item ~11 k cycles against 1.3-4.3 k of matrix work; MFMA-busy 0.24).  Here waves 0-3 (one per SIMD) own rows
+// [0, 128) of the block's 256-row item and waves 4-7 (their SIMD partners) rows [128, 256), each group with its OWN slab buffer; nothing but the read-only
+// weights is shared, so the groups need no ordering between them -- but s_barrier is block-wide, and both run the same two barriers per item: group 1 enters
+// its loop one barrier late, so between any two barriers one wave of every SIMD is in its matrix phase (LDS fragment reads + MFMAs) while its partner
+// requests / copies the next slab and runs the VALU + store work of its epilogue.  Same arithmetic per output element as conv_c64_mx_kernel (bit-identical
+// results); a slab is 128 + (K - 1) d rows per group (<= 192; K = 11: d <= 5, 184 rows -- 163 456 of the CU's 163 840 LDS bytes).
+template <int K>
+struct Conv64Mx2Geom {
+    static constexpr int C = 64, NB = 32, KG = (K + 1) / 2, KP = KG * 2;
+    static constexpr int GR = 128, XR = (K == 11) ? 184 : 192, MAXSPAN = XR - GR, EPITCH = NB * 4 + 16;
+    static constexpr int XHC = XR * 64 + 64;           // one K-chunk of a group's hi plane
+    static constexpr int WHB = K * NB * 64, WQB = KP * NB * 32, WSB = KP * NB * 2;
+    static constexpr int OFF_WH = 0, OFF_WQ = 2 * WHB, OFF_WS = OFF_WQ + 2 * WQB, OFF_X = OFF_WS + 2 * WSB;
+    static constexpr int XG = 2 * XHC + 2 * XR * 32 + 2 * XR * 4;       // one group's slab: hi (2 chunks), codes (2 planes), scales (2 planes)
+    static constexpr int OFF_ES = OFF_X + 2 * XG;
+    static constexpr int TOTAL = OFF_ES + 8 * 16 * EPITCH;
+    static constexpr int HI_N = (XR * 8 + 255) / 256;   // 16-byte units per thread: hi plane / code planes (4 XR units) / scale planes (8 XR bytes)
+    static_assert(OFF_X % 16 == 0 && XG % 16 == 0 && OFF_ES % 16 == 0 && TOTAL <= 160 * 1024 && 4 * XR <= 768 && 8 * XR / 16 <= 256, "LDS plan");
+};
+
+template <int K, int MODE, bool RPL = false>
+__global__ __launch_bounds__(512, 1) void conv_c64_mx2_kernel(const ConvGemmParams p) {
+    using G = Conv64Mx2Geom<K>;
+    constexpr int NB = G::NB, KG = G::KG, XR = G::XR, EPITCH = G::EPITCH, HI_N = G::HI_N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Wh = smem + G::OFF_WH;
+    char* const Wq = smem + G::OFF_WQ;
+    char* const Wsc = smem + G::OFF_WS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gi = wave >> 2, lw = wave & 3, ltid = tid & 255;          // group, wave inside the group, thread inside the group
+    char* const Xg = smem + G::OFF_X + gi * G::XG;                       // this group's slab
+    char* const Xh = Xg;                                                 // [chunk][row][64 B] swizzled
+    char* const Xq = Xg + 2 * G::XHC;                                    // [plane][row][32 B]
+    char* const Xsc = Xq + 2 * XR * 32;                                  // [plane][row][4]
+    char* const es = smem + G::OFF_ES + wave * 16 * EPITCH;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int dil = p.dil, hlo = p.center * dil;
+    const int ntiles = p.M / 256, nitems = ((ntiles + 7) >> 3) << 4;
+#define EV_C64_TILE(I) min((((I) >> 4) << 3) + ((I) & 7), ntiles - 1)
+#define EV_C64_OK(I) (((((I) >> 4) << 3) + ((I) & 7)) < ntiles)
+#define EV_C64_HALF(I) (((I) >> 3) & 1)
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    const int n0 = EV_C64_HALF(item) * NB;
+
+    // ---- this block's half of the weights -> LDS (all 512 threads)
+    {
+        const char* w16 = reinterpret_cast<const char*>(p.W);
+        for (int c = tid; c < 2 * K * NB * 4; c += 512) {
+            const int part = c & 3, row = (c >> 2) % (K * NB), ch = c / (4 * K * NB), tap = row >> 5, co = row & 31;
+            const long off = ((long)((n0 + co) * K + tap) * 64 + ch * 32) * 2 + part * 16;
+            *reinterpret_cast<uint4*>(Wh + ch * G::WHB + swz(row, part)) = *reinterpret_cast<const uint4*>(w16 + off);
+        }
+        const char* wm = reinterpret_cast<const char*>(p.W_mx);
+        for (int c = tid; c < 2 * G::WQB / 16; c += 512) {
+            const int pl = c / (G::WQB / 16), r = c % (G::WQB / 16), row = r >> 1, hf = r & 1;
+            *reinterpret_cast<uint4*>(Wq + pl * G::WQB + row * 32 + (hf << 4)) =
+                *reinterpret_cast<const uint4*>(wm + (size_t)(pl * 2 + (n0 >> 5)) * G::WQB + (size_t)r * 16);
+        }
+        for (int c = tid; c < 2 * G::WSB / 16; c += 512) {
+            const int pl = c / (G::WSB / 16), r = c % (G::WSB / 16);
+            *reinterpret_cast<uint4*>(Wsc + pl * G::WSB + r * 16) =
+                *reinterpret_cast<const uint4*>(wm + (size_t)4 * G::WQB + (size_t)(pl * 2 + (n0 >> 5)) * G::WSB + (size_t)r * 16);
+        }
+    }
+    const int er = lane >> 2, eg = lane & 3, eco = n0 + eg * 8;
+    const unsigned erbit = 1u << er;
+    f32x2 bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = p.bias ? f32x2{p.bias[eco + 2 * q], p.bias[eco + 2 * q + 1]} : f32x2{0.f, 0.f};
+    const f32x2 out_scale2 = f32x2{p.out_scale, p.out_scale};
+    const bool act_lrelu = p.act == ACT_LRELU;
+    const f32x2 act_slope2 = f32x2{p.act_slope, p.act_slope};
+    const bool has_planes = p.mxo_h != nullptr;
+    const f32x2 mxo_slope2 = f32x2{p.mxo_slope, p.mxo_slope};
+    const bool mxo_act = p.mxo_slope != 1.0f, scaled = p.out_scale != 1.0f;
+    const f32x2 res_inv2 = f32x2{p.res_inv_slope, p.res_inv_slope};
+    float* const o32 = p.out32;
+    const uint8_t* vptr = p.row_valid ? p.row_valid : g_row_always_valid;
+    const int vshift = p.row_valid ? p.valid_shift : 31;
+
+    // ---- slab staging of a group (256 threads, plain copies of the producer's planes): HI_N units of the hi plane per thread (unit u = ltid + 256 i ->
+    // row u >> 3, part u & 7), three of the code planes (u -> plane u / (2 XR), row (u % (2 XR)) >> 1, half u & 1), one of the scale planes (16 bytes = 4 rows).
+    // Units beyond the slab duplicate its last unit, rows beyond the conv's span re-read the span's last row (same data to the same address: harmless, and
+    // every lane consumes what it loads -- an un-consumed load leaves a pending write on its registers).
+    u32x4 xh[HI_N], xc[3], xs4;
+    const int last_row = G::GR - 1 + (K - 1) * dil;
+    unsigned hoff[HI_N], coff[3];
+    int hdst[HI_N], cdst[3];
+#pragma unroll
+    for (int i = 0; i < HI_N; ++i) {
+        const int r = min((ltid >> 3) + 32 * i, XR - 1);
+        hoff[i] = (unsigned)min(r, last_row) * 128u + (ltid & 7) * 16u;
+        hdst[i] = ((ltid >> 2) & 1) * G::XHC + swz(r, ltid & 3);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = min(ltid + 256 * j, 4 * XR - 1);
+        const int pl = u / (2 * XR), row = (u % (2 * XR)) >> 1, hf = u & 1;
+        coff[j] = (unsigned)min(row, last_row) * 32u + hf * 16u + (pl ? 0x80000000u : 0u);          // (bit 31: the remainder's code plane)
+        cdst[j] = pl * XR * 32 + row * 32 + (hf << 4);
+    }
+    const int su = min(ltid, 8 * XR / 16 - 1);
+    const int spl = su / (XR / 4), srow = (su % (XR / 4)) * 4;
+    const char* const hbase = reinterpret_cast<const char*>(p.A);
+    const char* const cbase0 = reinterpret_cast<const char*>(p.mx_x4[0]);
+    const char* const cbase1 = reinterpret_cast<const char*>(p.mx_x4[1]);
+    const char* const sbase = reinterpret_cast<const char*>(spl ? p.mx_xs[1] : p.mx_xs[0]) + srow * 4;
+    const int grow = gi * G::GR;                                     // the group's first row inside the block's 256-row item
+#define EV_C64_GLOAD(TILE)                                                                                 \
+    {                                                                                                      \
+        const long r00_ = (long)(TILE) * 256 + grow - hlo;                                                 \
+        const char* hb_ = hbase + r00_ * 128;                                                              \
+        const char* c0_ = cbase0 + r00_ * 32;                                                              \
+        const char* c1_ = cbase1 + r00_ * 32;                                                              \
+        _Pragma("unroll") for (int i = 0; i < HI_N; ++i) xh[i] = *reinterpret_cast<const u32x4*>(hb_ + hoff[i]); \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) xc[j] = *reinterpret_cast<const u32x4*>(((coff[j] >> 31) ? c1_ : c0_) + (coff[j] & 0x7fffffffu)); \
+        xs4 = *reinterpret_cast<const u32x4*>(sbase + r00_ * 4);                                           \
+    }
+#define EV_C64_SSTORE()                                                                                    \
+    {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < HI_N; ++i) *reinterpret_cast<u32x4*>(Xh + hdst[i]) = xh[i];  \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4*>(Xq + cdst[j]) = xc[j];     \
+        *reinterpret_cast<u32x4*>(Xsc + spl * XR * 4 + srow * 4) = xs4;                                    \
+    }
+
+    // block barrier of the main loop: LDS traffic retired, but NOT vmcnt (a __syncthreads() here would wait for the epilogue's global stores and for
+    // the next slab's requests at every phase boundary; what a phase needs from memory the compiler's own register waits provide)
+#define EV_C64_GROUP_BARRIER()                                   \
+    {                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    }
+    EV_C64_GLOAD(EV_C64_TILE(item))
+    EV_C64_SSTORE()
+    __syncthreads();
+    if (gi == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0 from here on
+    const int wrow0 = lw * 32 + fr;
+    for (; item < nitems; item += gridDim.x) {
+        const int tile = EV_C64_TILE(item);
+        const bool item_ok = EV_C64_OK(item);
+        const int nitem = item + (int)gridDim.x;
+        const int ntile = EV_C64_TILE(min(nitem, nitems - 1));
+        const int m0 = tile * 256 + grow;
+        // ---------------- memory requests of this item, oldest first
+        uint8_t vb = vptr[(m0 + lw * 32 + (lane & 31)) >> vshift];
+        float4 resv[2][2], accin[2][2];
+        u32x4 rph[2];
+        unsigned rpc[2], rps[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const long t = m0 + lw * 32 + it * 16 + er;
+            if constexpr (MODE >= 1 && RPL) {
+                rph[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.res) + (t * 64 + eco) * 2);
+                rpc[it] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p.res_x4) + t * 32 + (n0 >> 5) * 16 + eg * 4);
+                rps[it] = reinterpret_cast<const uint8_t*>(p.res_xs)[t * 4 + (n0 >> 5)];
+            } else if constexpr (MODE >= 1) {
+                const float* rp = reinterpret_cast<const float*>(p.res) + t * p.ldres + eco;
+                resv[it][0] = *reinterpret_cast<const float4*>(rp); resv[it][1] = *reinterpret_cast<const float4*>(rp + 4);
+            }
+            if constexpr (MODE == 2) {
+                const float* ap = p.acc32 + t * p.ldacc + eco;
+                accin[it][0] = *reinterpret_cast<const float4*>(ap); accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
+            }
+        }
+        EV_C64_GLOAD(ntile)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---------------- matrix phase: fp16 hi x hi tap by tap (two 32-channel chunks each), then the two fp4 cross terms, two taps per MFMA
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int r0 = wrow0 + t * dil;
+            const int xo = r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                uint4 wf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Wh + ch * G::WHB + swz(t * 32 + a * 16 + fr, fq));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    uint4 xf = *reinterpret_cast<const uint4*>(Xh + ch * G::XHC + xo + b * 16 * 64);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf[a]), *reinterpret_cast<half8*>(&xf), acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const int tw = 2 * g + (fq >> 1), hf = fq & 1;
+            const int rq = wrow0 + min(tw, K - 1) * dil;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                uint4 wq[2], xq[2];
+                int ws[2], xs[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int wr = tw * 32 + a * 16 + fr;
+                    wq[a] = *reinterpret_cast<const uint4*>(Wq + pl * G::WQB + wr * 32 + (hf << 4));
+                    ws[a] = *reinterpret_cast<const uint8_t*>(Wsc + pl * G::WSB + wr * 2 + hf);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int rr = rq + b * 16;
+                    xq[b] = *reinterpret_cast<const uint4*>(Xq + pl * XR * 32 + rr * 32 + (hf << 4));
+                    xs[b] = *reinterpret_cast<const uint8_t*>(Xsc + pl * XR * 4 + rr * 4 + hf);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) mfma_mx_inplace(acc[a][b], wq[a], xq[b], ws[a], xs[b]);
+            }
+        }
+        EV_C64_GROUP_BARRIER()                 // every wave of the group is done with the slab (the other group: its new slab is complete)
+        EV_C64_SSTORE()                        // the next item's slab replaces it
+        // ---------------- epilogue: 16-row passes through the wave's transposing scratch
+        const unsigned vmask = (unsigned)__builtin_amdgcn_ballot_w64(vb != 0 && lane < 32);
+        f32x2 vv[2][4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int a = 0; a < 2; ++a) *reinterpret_cast<f32x4*>(es + fr * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][it];
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + er * EPITCH + eg * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + er * EPITCH + eg * 32 + 16);
+            vv[it][0] = f32x2{v0[0], v0[1]}; vv[it][1] = f32x2{v0[2], v0[3]}; vv[it][2] = f32x2{v1[0], v1[1]}; vv[it][3] = f32x2{v1[2], v1[3]};
+        }
+        uint4 pho[2];
+        unsigned pch[2], pcl[2], pbh[2], pbl[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool valid = (vmask & (erbit << (it * 16))) != 0u;
+            f32x2* v = vv[it];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += bv[q];
+            if (act_lrelu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = lrelu2(v[q], act_slope2);
+            }
+            if constexpr (MODE >= 1) {
+                f32x2 rr[4];
+                if constexpr (RPL) {
+                    const half2v* h = reinterpret_cast<const half2v*>(&rph[it]);
+                    const float sc = __uint_as_float(rps[it] << 23);
+                    rr[0] = __builtin_convertvector(h[0], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 0);
+                    rr[1] = __builtin_convertvector(h[1], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 1);
+                    rr[2] = __builtin_convertvector(h[2], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 2);
+                    rr[3] = __builtin_convertvector(h[3], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(rpc[it], sc, 3);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 t2 = rr[q] * res_inv2;
+                        rr[q] = f32x2{min_raw(rr[q][0], t2[0]), min_raw(rr[q][1], t2[1])};
+                    }
+                } else {
+                    rr[0] = f32x2{resv[it][0].x, resv[it][0].y}; rr[1] = f32x2{resv[it][0].z, resv[it][0].w};
+                    rr[2] = f32x2{resv[it][1].x, resv[it][1].y}; rr[3] = f32x2{resv[it][1].z, resv[it][1].w};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += rr[q];
+                if (scaled) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= out_scale2;
+                }
+            }
+            if constexpr (MODE == 2) {
+                v[0] += f32x2{accin[it][0].x, accin[it][0].y}; v[1] += f32x2{accin[it][0].z, accin[it][0].w};
+                v[2] += f32x2{accin[it][1].x, accin[it][1].y}; v[3] += f32x2{accin[it][1].z, accin[it][1].w};
+            }
+            if (vmask != 0xffffffffu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q][0] = valid ? v[q][0] : 0.f; v[q][1] = valid ? v[q][1] : 0.f; }
+            }
+            if (has_planes) {
+                f32x2 am[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) am[q] = v[q];
+                if (mxo_act) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) am[q] = lrelu2(v[q], mxo_slope2);
+                }
+                mx_quant8(am, pho[it], pch[it], pcl[it], pbh[it], pbl[it]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const long t = m0 + lw * 32 + it * 16 + er;
+            const f32x2* v = vv[it];
+            if (item_ok && o32) {
+                float* op = o32 + t * p.ldo + eco;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
+            }
+            if (has_planes && item_ok) {
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + (t * 64 + eco) * 2) = pho[it];
+                *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + t * 32 + (n0 >> 5) * 16 + eg * 4) = pch[it];
+                *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + t * 32 + (n0 >> 5) * 16 + eg * 4) = pcl[it];
+                if (eg == 0) {
+                    reinterpret_cast<uint8_t*>(p.mxo_qs[0])[t * 4 + (n0 >> 5)] = (uint8_t)pbh[it];
+                    reinterpret_cast<uint8_t*>(p.mxo_qs[1])[t * 4 + (n0 >> 5)] = (uint8_t)pbl[it];
+                }
+            }
+        }
+        EV_C64_GROUP_BARRIER()                 // the group's new slab is complete (the other group: done with its old one)
+    }
+    if (gi == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two groups match
+#undef EV_C64_GROUP_BARRIER
+#undef EV_C64_GLOAD
+#undef EV_C64_SSTORE
+#undef EV_C64_TILE
+#undef EV_C64_HALF
+#undef EV_C64_OK
+}
+
 template <int K>
 static hipError_t conv64_mx_attr() {
     hipError_t e = hipSuccess, r;
@@ -375,6 +700,11 @@ static hipError_t conv64_mx_attr() {
     r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
     r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
     r = hipFuncSetAttribute((const void*)conv_c64_mx_kernel<K, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64MxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_c64_mx2_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64Mx2Geom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_c64_mx2_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64Mx2Geom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_c64_mx2_kernel<K, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64Mx2Geom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_c64_mx2_kernel<K, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64Mx2Geom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_c64_mx2_kernel<K, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv64Mx2Geom<K>::TOTAL); if (r != hipSuccess) e = r;
     return e;
 }
 static hipError_t conv64_mx_set_attributes() {
@@ -402,6 +732,20 @@ static void launch_conv64_mx(const ConvGemmParams& p, hipStream_t s) {
     const int grid = nitems <= n_cu ? nitems : (n_cu / 16) * 16;           // a multiple of 16 keeps a block's channel half fixed
     const int mode = p.acc32 ? 2 : (p.res ? 1 : 0);
     const bool rpl = p.res && p.res_dtype == DT_MX;
+    // two-group schedule (conv_c64_mx2_kernel) whenever the group's slab holds the conv's span; reserved0 bit 2: in-process A/B (lock-step kernel)
+#define EV_C64_LAUNCH2(KK)                                                                                                        \
+        if (mode == 2 && rpl) hipLaunchKernelGGL((conv_c64_mx2_kernel<KK, 2, true>), dim3(grid), dim3(512), Conv64Mx2Geom<KK>::TOTAL, s, p);      \
+        else if (mode == 1 && rpl) hipLaunchKernelGGL((conv_c64_mx2_kernel<KK, 1, true>), dim3(grid), dim3(512), Conv64Mx2Geom<KK>::TOTAL, s, p); \
+        else if (mode == 2) hipLaunchKernelGGL((conv_c64_mx2_kernel<KK, 2>), dim3(grid), dim3(512), Conv64Mx2Geom<KK>::TOTAL, s, p); \
+        else if (mode == 1) hipLaunchKernelGGL((conv_c64_mx2_kernel<KK, 1>), dim3(grid), dim3(512), Conv64Mx2Geom<KK>::TOTAL, s, p); \
+        else hipLaunchKernelGGL((conv_c64_mx2_kernel<KK, 0>), dim3(grid), dim3(512), Conv64Mx2Geom<KK>::TOTAL, s, p);
+    const int span = (p.taps - 1) * p.dil;
+    if (!(p.reserved0 & 4) && !(p.reserved0 >> 4)) {
+        if (p.taps == 3 && span <= Conv64Mx2Geom<3>::MAXSPAN) { EV_C64_LAUNCH2(3) return; }
+        if (p.taps == 7 && span <= Conv64Mx2Geom<7>::MAXSPAN) { EV_C64_LAUNCH2(7) return; }
+        if (p.taps == 11 && span <= Conv64Mx2Geom<11>::MAXSPAN) { EV_C64_LAUNCH2(11) return; }
+    }
+#undef EV_C64_LAUNCH2
 #define EV_C64_LAUNCH(KK)                                                                                                        \
         if (mode == 2 && rpl) hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 2, true>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p);      \
         else if (mode == 1 && rpl) hipLaunchKernelGGL((conv_c64_mx_kernel<KK, 1, true>), dim3(grid), dim3(512), Conv64MxGeom<KK>::TOTAL, s, p); \

@@ -2367,7 +2367,26 @@ int launch_resblock_pair_c32_mx(const ResPairParams& p, hipStream_t s) {
     if (!p.w1_mx || !p.w2_mx || !e.out32 || e.out16 || e.add16_a || e.post_lrelu || e.seq_bias || e.mxo_h || !(p.k == 3 || p.k == 7 || p.k == 11) ||
         (p.k - 1) / 2 * (p.dil + 1) * 2 + 256 > 320 || p.ldx != 32) return -1;
     const int n_cu = device_cus();
-    const int h2 = (p.k - 1) / 2, bmo = 256 - 2 * h2;
+    const int h2 = (p.k - 1) / 2;
+    // two-group schedule (resblock_pair_c32_mx2_kernel: 128-row tiles, one per 4-wave group) once there are enough tiles to keep every group of every
+    // CU busy; epi.reserved0 bit 2: in-process A/B (lock-step kernel).  Which kernel a launch takes depends on M, the result does not (bit-identical).
+    {
+        const int bmo2 = 128 - 2 * h2, ntiles2 = (p.M + bmo2 - 1) / bmo2;
+        if (!(e.reserved0 & 4) && ntiles2 >= 2) {
+            const int grid2 = (ntiles2 + 1) / 2 < n_cu ? (ntiles2 + 1) / 2 : n_cu;
+#define EV_PMX2_LAUNCH(KK)                                                                                                          \
+            if (e.acc32) hipLaunchKernelGGL((resblock_pair_c32_mx2_kernel<KK, 1>), dim3(grid2), dim3(512), PairMx2Geom<KK>::TOTAL, s, p);   \
+            else hipLaunchKernelGGL((resblock_pair_c32_mx2_kernel<KK, 0>), dim3(grid2), dim3(512), PairMx2Geom<KK>::TOTAL, s, p);
+            switch (p.k) {
+                case 3: EV_PMX2_LAUNCH(3) break;
+                case 7: EV_PMX2_LAUNCH(7) break;
+                default: EV_PMX2_LAUNCH(11) break;
+            }
+#undef EV_PMX2_LAUNCH
+            return 0;
+        }
+    }
+    const int bmo = 256 - 2 * h2;
     const int ntiles = (p.M + bmo - 1) / bmo;
     const int grid = ntiles < n_cu ? ntiles : n_cu;
 #define EV_PMX_LAUNCH(KK)                                                                                                         \

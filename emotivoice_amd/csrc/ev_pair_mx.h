@@ -296,11 +296,301 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx_kernel(const ResP
 #undef EV_PMX_VMASK
 }
 
+
+// ---- Round 4: the same pair with the block's eight waves split into TWO GROUPS one barrier apart (see conv_c64_mx2_kernel).  Waves 0-3 and waves 4-7
+// (SIMD partners) each own a 128-row tile of their own (BMO = 128 - 2 H2 output rows), with private slab and xt plane sets; only the read-only weights are
+// shared.  Both groups run the same two barriers per tile, group 1 one barrier late: while one wave of a SIMD is in [requests, conv1, xt -> LDS] its partner
+// is in [next slab -> LDS, conv2, epilogue], so the latency chains of one group (global loads, LDS round trips of the quantisers, store issue) sit beside the
+// other group's matrix work instead of beside an identical copy of themselves.  Same arithmetic per output element: bit-identical to the lock-step kernel.
+template <int K>
+struct PairMx2Geom {
+    static constexpr int C = 32, H2 = (K - 1) / 2, GR = 128, BMO = GR - 2 * H2, KG = (K + 3) / 4, KP = KG * 4;
+    static constexpr int XR = 192, TR = 144, EPITCH = C * 4 + 16;
+    static constexpr int WHB = K * C * 64, WQB = KP * C * 16, WSB = KP * C;
+    static constexpr int OFF_WH = 0, OFF_WQ = 2 * WHB, OFF_WS = OFF_WQ + 4 * WQB, OFF_G = OFF_WS + 4 * WSB;
+    static constexpr int G_XH = 0, G_XQ = XR * 64, G_XS = G_XQ + 2 * XR * 16, G_TH = G_XS + 2 * XR, G_TQ = G_TH + TR * 64, G_TS = G_TQ + 2 * TR * 16;
+    static constexpr int GB = G_TS + 2 * TR;            // one group's slab + xt plane sets
+    static constexpr int OFF_ES = OFF_G + 2 * GB;
+    static constexpr int TOTAL = OFF_ES + 8 * 16 * EPITCH;
+    static_assert(OFF_G % 16 == 0 && GB % 16 == 0 && G_TH % 16 == 0 && OFF_ES % 16 == 0 && TOTAL <= 160 * 1024 && GR + K - 1 <= TR, "LDS plan");
+};
+
+template <int K, int ACCMODE>
+__global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx2_kernel(const ResPairParams p) {
+    using G = PairMx2Geom<K>;
+    constexpr int C = G::C, H2 = G::H2, BMO = G::BMO, KG = G::KG, XR = G::XR, TR = G::TR, EPITCH = G::EPITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const W1h = smem + G::OFF_WH;
+    char* const W2h = W1h + G::WHB;
+    char* const Wq = smem + G::OFF_WQ;
+    char* const Wsc = smem + G::OFF_WS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gi = wave >> 2, lw = wave & 3, ltid = tid & 255;
+    char* const gb = smem + G::OFF_G + gi * G::GB;
+    char* const Xh = gb + G::G_XH;
+    char* const Xq = gb + G::G_XQ;        // [plane][XR][16]
+    char* const Xsc = gb + G::G_XS;       // [plane][XR]
+    char* const Th = gb + G::G_TH;
+    char* const Tq = gb + G::G_TQ;        // [plane][TR][16]
+    char* const Tsc = gb + G::G_TS;       // [plane][TR]
+    char* const es = smem + G::OFF_ES + wave * 16 * EPITCH;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int dil = p.dil, h1 = H2 * dil;
+    const int x_pitch = p.ldx * 4;
+    const char* xg = reinterpret_cast<const char*>(p.x);
+    const int ntiles = (p.M + BMO - 1) / BMO;
+    const ConvGemmParams& e = p.epi;
+    const int gmin = p.gmax ? p.gmin : 0, gmax = p.gmax ? p.gmax : p.M;
+
+    // ---- weights -> LDS, once per block (all 512 threads)
+    for (int c = tid; c < K * C * 4; c += 512) {
+        const int row = c >> 2, part = c & 3, tap = row >> 5, co = row & 31;
+        const long off = ((long)(co * K + tap) * C) * 2 + part * 16;
+        *reinterpret_cast<uint4*>(W1h + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w1) + off);
+        *reinterpret_cast<uint4*>(W2h + swz(row, part)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w2) + off);
+    }
+    for (int c = tid; c < 2 * G::WQB / 16; c += 512) {
+        *reinterpret_cast<uint4*>(Wq + c * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w1_mx) + c * 16);
+        *reinterpret_cast<uint4*>(Wq + 2 * G::WQB + c * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w2_mx) + c * 16);
+    }
+    for (int c = tid; c < 2 * G::WSB / 16; c += 512) {
+        *reinterpret_cast<uint4*>(Wsc + c * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w1_mx) + 2 * G::WQB + c * 16);
+        *reinterpret_cast<uint4*>(Wsc + 2 * G::WSB + c * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w2_mx) + 2 * G::WQB + c * 16);
+    }
+    f32x2 b1v[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b1v[a][q] = f32x2{p.b1[a * 16 + 4 * fq + 2 * q], p.b1[a * 16 + 4 * fq + 2 * q + 1]};
+    const int er = lane >> 2, eg = lane & 3, eco = eg * 8;
+    const unsigned frbit = 1u << fr, erbit = 1u << er;
+    f32x2 b2v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b2v[q] = e.bias ? f32x2{e.bias[eco + 2 * q], e.bias[eco + 2 * q + 1]} : f32x2{0.f, 0.f};
+    const f32x2 out_scale2 = f32x2{e.out_scale, e.out_scale};
+    const f32x2 slope01 = f32x2{0.1f, 0.1f};
+    float* const o32 = e.out32;
+    char* const trash = g_store_trash + lane * 64;
+    const uint8_t* vptr = e.row_valid ? e.row_valid : g_row_always_valid;
+    const int vshift = e.row_valid ? e.valid_shift : 31;
+#define EV_PMX_VROW(TILE) ((TILE) * BMO - H2 + lw * 32 + lane)
+#define EV_PMX_VLOAD(TILE, DST) { const int g_ = EV_PMX_VROW(TILE); DST = vptr[min(max(g_, gmin), gmax - 1) >> vshift]; }
+#define EV_PMX_VMASK(TILE, SRC) __builtin_amdgcn_ballot_w64((SRC) != 0 && EV_PMX_VROW(TILE) >= gmin && EV_PMX_VROW(TILE) < gmax)
+
+    // ---- slab staging of a group: a thread owns three (row, 8-channel quarter) units of the 192-row slab: rows (ltid >> 2) + {0, 64, 128}
+    float4 xr[3][2];
+    const int xq = ltid & 3;
+    const char* const xgt = xg + xq * 32;
+    const int xrow2 = min((ltid >> 2) + 128, G::GR - 1 + 2 * h1 + 2 * H2);      // rows beyond the convs' span re-read the last needed row
+    const int drow[3] = {ltid >> 2, (ltid >> 2) + 64, (ltid >> 2) + 128};
+#define EV_PMX_ROW(G_) min((G_), gmax + 63)
+#define EV_PMX_GLOAD(TILE)                                                                                 \
+    {                                                                                                      \
+        const int g0_ = (TILE) * BMO - H2 - h1 + (ltid >> 2);                                              \
+        const int g2_ = (TILE) * BMO - H2 - h1 + xrow2;                                                    \
+        const char* q0_ = xgt + (long)EV_PMX_ROW(g0_) * x_pitch;                                           \
+        const char* q1_ = xgt + (long)EV_PMX_ROW(g0_ + 64) * x_pitch;                                      \
+        const char* q2_ = xgt + (long)EV_PMX_ROW(g2_) * x_pitch;                                           \
+        xr[0][0] = *reinterpret_cast<const float4*>(q0_); xr[0][1] = *reinterpret_cast<const float4*>(q0_ + 16); \
+        xr[1][0] = *reinterpret_cast<const float4*>(q1_); xr[1][1] = *reinterpret_cast<const float4*>(q1_ + 16); \
+        xr[2][0] = *reinterpret_cast<const float4*>(q2_); xr[2][1] = *reinterpret_cast<const float4*>(q2_ + 16); \
+    }
+#define EV_PMX_SSTORE()                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                        \
+        f32x2 a_[4] = {lrelu2(f32x2{xr[i][0].x, xr[i][0].y}, slope01), lrelu2(f32x2{xr[i][0].z, xr[i][0].w}, slope01), \
+                       lrelu2(f32x2{xr[i][1].x, xr[i][1].y}, slope01), lrelu2(f32x2{xr[i][1].z, xr[i][1].w}, slope01)}; \
+        uint4 ho_; unsigned ch_, cl_, bh_, bl_;                                                            \
+        mx_quant8(a_, ho_, ch_, cl_, bh_, bl_);                                                            \
+        *reinterpret_cast<uint4*>(Xh + swz(drow[i], xq)) = ho_;                                            \
+        *reinterpret_cast<unsigned*>(Xq + drow[i] * 16 + xq * 4) = ch_;                                    \
+        *reinterpret_cast<unsigned*>(Xq + XR * 16 + drow[i] * 16 + xq * 4) = cl_;                          \
+        if (xq == 0) { Xsc[drow[i]] = (char)bh_; Xsc[XR + drow[i]] = (char)bl_; }                          \
+    }
+#define EV_PMX_CONV(XH, XQ, XS, NR, WH, CONV, DIL)                                                         \
+    {                                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < K; ++t) {                                                    \
+            const int r0 = wrow0 + t * (DIL);                                                              \
+            const char* xp = (XH) + r0 * 64 + ((fq ^ ((r0 >> 1) & 3)) << 4);                               \
+            uint4 wf_[2];                                                                                  \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a) wf_[a] = *reinterpret_cast<const uint4*>((WH) + swz(t * 32 + a * 16 + fr, fq)); \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                \
+                uint4 xf_ = *reinterpret_cast<const uint4*>(xp + b * 16 * 64);                             \
+                _Pragma("unroll") for (int a = 0; a < 2; ++a)                                              \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wf_[a]), *reinterpret_cast<half8*>(&xf_), acc[a][b], 0, 0, 0); \
+            }                                                                                              \
+        }                                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                                   \
+            const int tw = 4 * g + fq;                                                                     \
+            const int rq = wrow0 + min(tw, K - 1) * (DIL);                                                 \
+            _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                             \
+                uint4 wq_[2], xq_[2];                                                                      \
+                int ws_[2], xs_[2];                                                                        \
+                _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                            \
+                    wq_[a] = *reinterpret_cast<const uint4*>(Wq + ((CONV) * 2 + pl) * G::WQB + (tw * 32 + a * 16 + fr) * 16); \
+                    ws_[a] = *reinterpret_cast<const uint8_t*>(Wsc + ((CONV) * 2 + pl) * G::WSB + tw * 32 + a * 16 + fr); \
+                }                                                                                          \
+                _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                            \
+                    xq_[b] = *reinterpret_cast<const uint4*>((XQ) + pl * (NR) * 16 + (rq + b * 16) * 16);  \
+                    xs_[b] = *reinterpret_cast<const uint8_t*>((XS) + pl * (NR) + rq + b * 16);            \
+                }                                                                                          \
+                _Pragma("unroll") for (int b = 0; b < 2; ++b)                                              \
+                    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                          \
+                        mfma_mx_inplace(acc[a][b], wq_[a], xq_[b], ws_[a], xs_[b]);                          \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    // block barrier of the main loop: LDS traffic retired, vmcnt left alone (see conv_c64_mx2_kernel)
+#define EV_PMX_GROUP_BARRIER()                                   \
+    {                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    }
+
+    // tile stream of a group: tiles 2 (b + n grid) + gi; both groups run the same number of iterations (a tile index beyond the last recomputes
+    // the last tile and stores nothing)
+    const int niter = (ntiles + 2 * (int)gridDim.x - 1) / (2 * (int)gridDim.x);
+    int tq = 2 * (int)blockIdx.x + gi;
+    int tile = min(tq, ntiles - 1);
+    unsigned long long vmask;
+    {
+        uint8_t vb;
+        EV_PMX_GLOAD(tile)
+        EV_PMX_VLOAD(tile, vb)
+        EV_PMX_SSTORE()
+        vmask = EV_PMX_VMASK(tile, vb);
+    }
+    __syncthreads();
+    if (gi == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0 from here on
+    const int wrow0 = lw * 32 + fr;
+    for (int it_ = 0; it_ < niter; ++it_, tq += 2 * (int)gridDim.x) {
+        tile = min(tq, ntiles - 1);
+        const int next = min(tq + 2 * (int)gridDim.x, ntiles - 1);
+        const int m0 = tile * BMO;
+        const int t_end = tq < ntiles ? min(m0 + BMO, p.M) : m0;          // (a repeated tile stores nothing)
+        float4 resv[2][2], accin[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = max(min(m0 + lw * 32 + it * 16 + er, t_end - 1), 0);
+            const char* rp = xg + (long)t * x_pitch + eg * 32;
+            resv[it][0] = *reinterpret_cast<const float4*>(rp);
+            resv[it][1] = *reinterpret_cast<const float4*>(rp + 16);
+            if constexpr (ACCMODE == 1) {
+                const float* ap = e.acc32 + (long)t * e.ldacc + eco;
+                accin[it][0] = *reinterpret_cast<const float4*>(ap);
+                accin[it][1] = *reinterpret_cast<const float4*>(ap + 4);
+            }
+        }
+        uint8_t vb_next;
+        EV_PMX_GLOAD(next)
+        EV_PMX_VLOAD(next, vb_next)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][2];
+        // ---------------- conv1 (dilation d): the group's 128 rows, global rows m0 - H2 + r1
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        EV_PMX_CONV(Xh, Xq, Xsc, XR, W1h, 0, dil)
+        const unsigned xtmask = (unsigned)vmask;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r1 = wrow0 + b * 16;
+            const bool valid = (xtmask & (frbit << (b * 16))) != 0u;
+            f32x2 v[2][2];
+            half2v hh[2][2];
+            f32x2 hf[2][2], lf[2][2];
+            float mh = 0.f, ml = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                v[a][0] = lrelu2(f32x2{acc[a][b][0], acc[a][b][1]} + b1v[a][0], slope01);
+                v[a][1] = lrelu2(f32x2{acc[a][b][2], acc[a][b][3]} + b1v[a][1], slope01);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    v[a][q][0] = valid ? v[a][q][0] : 0.f; v[a][q][1] = valid ? v[a][q][1] : 0.f;
+                    hh[a][q] = __builtin_convertvector(v[a][q], half2v);
+                    hf[a][q] = __builtin_convertvector(hh[a][q], f32x2);
+                    lf[a][q] = v[a][q] - hf[a][q];
+                    mh = max3_abs_raw(hf[a][q][0], hf[a][q][1], mh);
+                    ml = max3_abs_raw(lf[a][q][0], lf[a][q][1], ml);
+                }
+            }
+            mh = max_xor16_raw(max_xor32_raw(mh));
+            ml = max_xor16_raw(max_xor32_raw(ml));
+            const unsigned bh = mx_scale_byte(mh), bl = mx_scale_byte(ml);
+            const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                uint2 w;
+                w.x = *reinterpret_cast<unsigned*>(&hh[a][0]); w.y = *reinterpret_cast<unsigned*>(&hh[a][1]);
+                const int co = a * 16 + 4 * fq;
+                *reinterpret_cast<uint2*>(Th + swz(r1, co >> 3) + (co & 7) * 2) = w;
+                unsigned ch = 0, cl = 0;
+                ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[a][0][0], hf[a][0][1], sh, 0);
+                ch = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ch, hf[a][1][0], hf[a][1][1], sh, 1);
+                cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[a][0][0], lf[a][0][1], sl, 0);
+                cl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(cl, lf[a][1][0], lf[a][1][1], sl, 1);
+                *reinterpret_cast<unsigned short*>(Tq + r1 * 16 + (co >> 1)) = (unsigned short)ch;
+                *reinterpret_cast<unsigned short*>(Tq + TR * 16 + r1 * 16 + (co >> 1)) = (unsigned short)cl;
+            }
+            if (fq == 0) { Tsc[r1] = (char)bh; Tsc[TR + r1] = (char)bl; }
+        }
+        EV_PMX_GROUP_BARRIER()          // every wave of the group is done with the slab; xt is complete
+        EV_PMX_SSTORE()                 // the next tile's slab replaces the current one (conv2 only reads xt)
+        const unsigned long long vmask_next = EV_PMX_VMASK(next, vb_next);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        EV_PMX_CONV(Th, Tq, Tsc, TR, W2h, 1, 1)
+        const unsigned outmask = (unsigned)(vmask >> H2);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = m0 + lw * 32 + it * 16 + er;
+            const bool rowok = t < t_end;
+            const bool valid = (outmask & (erbit << (it * 16))) != 0u;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int a = 0; a < 2; ++a) *reinterpret_cast<f32x4*>(es + fr * EPITCH + (a * 16 + 4 * fq) * 4) = acc[a][it];
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(es + er * EPITCH + eg * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(es + er * EPITCH + eg * 32 + 16);
+            f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
+            const f32x2 rr[4] = {f32x2{resv[it][0].x, resv[it][0].y}, f32x2{resv[it][0].z, resv[it][0].w},
+                                 f32x2{resv[it][1].x, resv[it][1].y}, f32x2{resv[it][1].z, resv[it][1].w}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (v[q] + b2v[q] + rr[q]) * out_scale2;
+            if constexpr (ACCMODE == 1) {
+                v[0] += f32x2{accin[it][0].x, accin[it][0].y}; v[1] += f32x2{accin[it][0].z, accin[it][0].w};
+                v[2] += f32x2{accin[it][1].x, accin[it][1].y}; v[3] += f32x2{accin[it][1].z, accin[it][1].w};
+            }
+            float* op = rowok ? o32 + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
+            *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        vmask = vmask_next;
+        EV_PMX_GROUP_BARRIER()          // the group's new slab is complete; xt may be overwritten
+    }
+    if (gi == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two groups match
+#undef EV_PMX_GROUP_BARRIER
+#undef EV_PMX_CONV
+#undef EV_PMX_SSTORE
+#undef EV_PMX_GLOAD
+#undef EV_PMX_ROW
+#undef EV_PMX_VROW
+#undef EV_PMX_VLOAD
+#undef EV_PMX_VMASK
+}
+
 template <int K>
 static hipError_t pair_mx_attr() {
     hipError_t e = hipSuccess, r;
     r = hipFuncSetAttribute((const void*)resblock_pair_c32_mx_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PairMxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
     r = hipFuncSetAttribute((const void*)resblock_pair_c32_mx_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PairMxGeom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)resblock_pair_c32_mx2_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PairMx2Geom<K>::TOTAL); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)resblock_pair_c32_mx2_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PairMx2Geom<K>::TOTAL); if (r != hipSuccess) e = r;
     return e;
 }
 static hipError_t pair_mx_set_attributes() {

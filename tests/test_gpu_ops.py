@@ -964,6 +964,25 @@ def test_conv_c64_mx(lib, k, dil, mode, M):
             assert _rel(rec, refs["emu"]) < 1e-4, (k, dil, mode, _rel(rec, refs["emu"]))
             assert _rel(gh.double(), refs["emu"]) < 6e-4 and not ps.h[PAD:PAD + M].cpu().numpy()[~vr.numpy()].any()
     assert _rel(refs["emu"], refs["exact"]) > 1e-6
+    # the two-group schedule (conv_c64_mx2_kernel, the launcher's choice above) against the lock-step kernel (reserved0 bit 2): the same arithmetic
+    # per output element, so every output must agree bit for bit
+    out2 = acc.clone() if mode == "conv2acc" else torch.full((M, Cc), 7.0, device="cuda")
+    ps2 = _PlaneSet(M, Cc)
+    if mode == "conv2acc":
+        d.acc32 = out2.data_ptr()
+    if want32:
+        d.out32 = out2.data_ptr()
+    if planes_out:
+        ps2.out_fields(d, 1.0 if mode == "conv1" else 0.1)
+        d.mxo_logC = 6
+    d.reserved0 = 4
+    _launch(lib, d)
+    if want32:
+        assert torch.equal(out, out2), (k, dil, mode)
+    if planes_out:
+        assert torch.equal(ps.h[PAD:PAD + M], ps2.h[PAD:PAD + M])
+        for i in range(2):
+            assert torch.equal(ps.q4[i][PAD:PAD + M], ps2.q4[i][PAD:PAD + M]) and torch.equal(ps.qs[i][0, PAD:PAD + M, :2], ps2.qs[i][0, PAD:PAD + M, :2])
 
 
 def _host_plane_set(a):
