@@ -249,6 +249,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx_kernel(const ConvGemmParam
                     for (int a = 0; a < 2; ++a) mfma_mx_inplace(acc[a][b], wq[a], xq[b], ws[a], xs[b]);
             }
         }
+        mfma_asm_fence(acc);
         }
         EV_C64_TICK(1)
         __syncthreads();          // every wave is done with the slab
@@ -590,6 +591,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64_mx2_kernel(const ConvGemmPara
                     for (int a = 0; a < 2; ++a) mfma_mx_inplace(acc[a][b], wq[a], xq[b], ws[a], xs[b]);
             }
         }
+        mfma_asm_fence(acc);
         EV_C64_GROUP_BARRIER()                 // every wave of the group is done with the slab (the other group: its new slab is complete)
         EV_C64_SSTORE()                        // the next item's slab replaces it
         // ---------------- epilogue: 16-row passes through the wave's transposing scratch

@@ -903,6 +903,20 @@ __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigne
 __device__ __forceinline__ void mfma_inplace(f32x4& c, const half8& a, const half8& b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// Software wait states between the LAST inline-asm MFMA of a sequence and the first VALU / LDS / VMEM instruction that reads (or overwrites) its
+// accumulators.  gfx9 has no hardware interlock for "XDL write VGPR -> non-MFMA read": hipcc's hazard recognizer pads MFMAs it emits itself, but cannot see
+// into an asm statement.  Found in round 4 by the bit-identity test of the two-group pair kernel: resblock_pair_c32_mx_kernel<3, 1> (round 3's product) read
+// conv1's accumulators for the xt quantiser two MFMA issue slots after the last block-scaled MFMA and, depending on how the SIMD's other wave was scheduled,
+// sometimes got the value from BEFORE it -- one fp4 cross term (2^-11 of the result, 3e-4 absolute on unit-variance data) missing in a few rows, run to run.
+// 20 wait states cover the 16-pass worst case of the gfx940 / gfx950 tables (XDL write -> VALU read: passes + 3).
+template <int NA, int NB>
+__device__ __forceinline__ void mfma_asm_fence(f32x4 (&acc)[NA][NB]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(acc[a][b]));          // (every later use of an accumulator is ordered behind the nops)
+}
 
 // Tuning builds only (build.py --variant <tag> EV_PH_ABLATE=<bits>): drop one ingredient of the main loop to see what the phases wait
 // for -- 1: no MFMAs, 2: no fragment reads, 4: no DMA requests, 8: no phase barriers, 16: no epilogue.  Results are garbage by design.
@@ -1125,6 +1139,7 @@ __device__ __forceinline__ void conv_gemm_phased_body(const ConvGemmParams& p, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!ONE_BAR && wc == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+    mfma_asm_fence(acc);
     EV_PH_TICK(5)
     if constexpr ((EV_PH_ABLATE & 16) == 0) {
         EV_TRACE_EPI_DUMMY

@@ -313,6 +313,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wc == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+    mfma_asm_fence(acc);
     }       // tile_live
 #ifdef EV_MX_ABL
     if ((p.reserved0 >> 4) & 2) {

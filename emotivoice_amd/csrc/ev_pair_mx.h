@@ -160,6 +160,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx_kernel(const ResP
                         mfma_mx_inplace(acc[a][b], wq_[a], xq_[b], ws_[a], xs_[b]);                          \
             }                                                                                              \
         }                                                                                                  \
+        mfma_asm_fence(acc);          /* the quantiser / the epilogue read the accumulators next */       \
     }
 
     int tile = blockIdx.x;                    // grid <= ntiles
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx2_kernel(const Res
                         mfma_mx_inplace(acc[a][b], wq_[a], xq_[b], ws_[a], xs_[b]);                          \
             }                                                                                              \
         }                                                                                                  \
+        mfma_asm_fence(acc);          /* the quantiser / the epilogue read the accumulators next */       \
     }
     // block barrier of the main loop: LDS traffic retired, vmcnt left alone (see conv_c64_mx2_kernel)
 #define EV_PMX_GROUP_BARRIER()                                   \

@@ -871,6 +871,29 @@ def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
     assert _rel(got, res["emu"]) < 5e-5, (k, dil, _rel(got, res["emu"]))
     assert _rel(got, res["exact"]) < 2e-4, (k, dil, _rel(got, res["exact"]))
     assert _rel(res["emu"], res["exact"]) > 1e-6
+    # the two-group schedule (resblock_pair_c32_mx2_kernel: the launcher's choice above) against the lock-step kernel (epi.reserved0 bit 2): same
+    # arithmetic per output element, 128- instead of 256-row tiles -- bit-identical outputs
+    out2 = acc.clone() if acc_in else torch.full((M, Cc), 7.0, device="cuda")
+    if acc_in:
+        e.acc32 = out2.data_ptr()
+    e.out32 = out2.data_ptr()
+    e.reserved0 = 4
+    torch.cuda.synchronize()
+    assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2), (k, dil, acc_in)
+    # ... and run to run: round 3's <3, accumulate-in> instantiation read conv1's accumulators too early after the last inline-asm MFMA (no hardware
+    # interlock, see mfma_asm_fence in ev_gemm.hip) and differed between identical launches in a few hundred rows
+    for dbg in (0, 4, 0):
+        out3 = acc.clone() if acc_in else torch.full((M, Cc), 7.0, device="cuda")
+        if acc_in:
+            e.acc32 = out3.data_ptr()
+        e.out32 = out3.data_ptr()
+        e.reserved0 = dbg
+        torch.cuda.synchronize()
+        assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, out3), (k, dil, acc_in, dbg)
 
 
 @pytest.mark.parametrize("k,dil,mode,M", [(3, 1, "conv1", 256 * 3), (3, 5, "conv2acc", 256 * 8), (7, 3, "conv1", 256 * 9), (7, 1, "conv2", 256 * 17),
