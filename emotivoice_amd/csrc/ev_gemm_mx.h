@@ -117,6 +117,11 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const int wt = wave & 3, wc = wave >> 2;          // wc is also the phase group: waves w and w + 4 share a SIMD
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
+    // (Round 4 tried a persistent tile loop here -- min(tiles, 2 x CUs) blocks walking the tile list with stride gridDim.x, bit-identical results --
+    // to save the ~5 us per residency round that a tile costs outside its K loop and epilogue (profiles/r3_k_mx_gemm_ablation.txt).  Measured
+    // in one process against one block per tile (profiles/r4_b_mx_persistent_ab.txt): 0-5 % SLOWER on every stage-0 / stage-1 shape.  The hardware's
+    // own dispatch back-fills a CU the moment a block retires; a static stride cannot, and the loop needs a block barrier per tile because the
+    // epilogue's transposing scratch aliases the staging buffers.  The fixed cost is pipeline fill latency, not block launch.)
     int bid = blockIdx.x;
     const int nblk = gridDim.x, nN = p.N >> 7;
     {

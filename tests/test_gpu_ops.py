@@ -699,6 +699,57 @@ def test_mx_conv_gemm_fp32_input(lib, Cc, N, k, dil, M):
     assert _rel(emu, exact) > 1e-6          # (the test would be vacuous if the emulation were exact)
 
 
+@pytest.mark.parametrize("Cc,N,k,dil,tiles_m", [(128, 128, 3, 5, 1100), (256, 256, 7, 1, 600), (128, 128, 11, 3, 530)])
+def test_mx_conv_gemm_long_tile_list_with_all_gap_tiles(lib, Cc, N, k, dil, tiles_m):
+    """conv_gemm_mx_kernel on more tiles than the chip holds at once (several residency rounds), with invalid row groups -- incl. whole all-gap
+    tiles, which skip the main loop and must still write zero rows / zero planes -- in the middle and at the end of the tile list: two identical
+    launches agree bit for bit (fp32 output AND the plane set of the result), and the rows around the gap match the fp64 emulation."""
+    torch.manual_seed(Cc + k + tiles_m)
+    M = 256 * tiles_m
+    full = torch.randn(M + 2 * PAD, Cc, device="cuda")
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x = full[PAD:PAD + M]
+    w = torch.randn(N, Cc, k, device="cuda") / math.sqrt(Cc * k)
+    bias = torch.randn(N, device="cuda")
+    wts = _mx_weights(w)
+    valid = torch.ones(M // 64, dtype=torch.uint8, device="cuda")
+    valid[:3] = 0
+    valid[400:409] = 0                      # rows 25600 .. 26175: two whole tiles and a partial one
+    valid[-7:] = 0
+    nb = lib.ev_op_mx_scratch_bytes(M, Cc)
+    scratch = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    outs = []
+    for dbg in (0, 0):
+        d = _mx_desc(lib, wts, M, N, Cc, k, dil, bias)
+        d.A, d.lda = x.data_ptr(), Cc
+        d.pro_lrelu, d.pro_slope = 1, 0.1
+        d.row_valid, d.valid_shift = valid.data_ptr(), 6
+        d.mx_scratch, d.mx_scratch_size = scratch.data_ptr(), nb
+        out = torch.full((M, N), 7.0, device="cuda")
+        ps = _PlaneSet(M, N)
+        d.out32 = out.data_ptr()
+        ps.out_fields(d, 0.1)
+        d.reserved0 = dbg
+        _launch(lib, d)
+        outs.append((out, ps))
+    (o0, p0), (o1, p1) = outs
+    assert torch.equal(o0, o1)
+    assert torch.equal(p0.h[PAD:PAD + M], p1.h[PAD:PAD + M])
+    for i in range(2):
+        assert torch.equal(p0.q4[i][PAD:PAD + M], p1.q4[i][PAD:PAD + M]) and torch.equal(p0.qs[i][:, PAD:PAD + M], p1.qs[i][:, PAD:PAD + M])
+    vrow = valid.bool().repeat_interleave(64)
+    assert float(o0[~vrow].abs().max()) == 0.0 and float(o0[vrow].abs().max()) > 0.1
+    # spot check against the fp64 emulation on the rows around the all-gap tiles
+    lo, hi = 25600 - 512, 26176 + 512
+    h = dil * (k - 1) // 2
+    a = _lrelu(full[PAD + lo - h:PAD + hi + h].float().cpu(), 0.1)
+    ah, qah, qal, _ = _mx_act_parts(a)
+    emu = _conv64(ah, wts["wh"], dil, k) + _conv64(qah, wts["qwl"], dil, k) + _conv64(qal, wts["qwh"], dil, k) + bias.double().cpu()
+    emu[~vrow[lo:hi].cpu()] = 0
+    assert _rel(o0[lo:hi].cpu().double(), emu) < 2e-6
+
+
 @pytest.mark.parametrize("Cc,k,dil,up", [(128, 7, 3, 0), (256, 3, 1, 0), (128, 11, 5, 0), (256, 3, 1, 4)])
 def test_mx_plane_set_chain(lib, Cc, k, dil, up):
     """The producer's epilogue writes the consumer's operand planes (EPI_MXP): (1) the planes equal the host quantiser applied to

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--ks", default="3,7,11")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--dbg", default="", help="comma list of reserved0 low bits to A/B in one run (8 = one block per tile instead of the persistent tile loop)")
     args = ap.parse_args()
     lib = _ffi.lib()
     Cc = args.c
@@ -48,12 +49,13 @@ def main():
     names = {0: "full"}
     if abl_build:
         names.update({1: "one-chunk main loop", 2: "no epilogue", 3: "one chunk, no epilogue", 4: "no plane stores", 8: "hi plane stored only", 16: "no scale bytes"})
+    dbgs = [int(x) for x in args.dbg.split(",")] if args.dbg else []
     for k in [int(x) for x in args.ks.split(",")]:
         wg = (np.random.default_rng(k).standard_normal((Cc, k, Cc)) / np.sqrt(Cc * k)).astype(np.float32)
         d_hi = torch.from_numpy(wg.astype(np.float16)).cuda()
         d_mx = torch.from_numpy(mxfp4.pack_weight_planes(wg)).cuda()
         for form in ("conv1", "conv2"):
-            for abl, nm in list(names.items()) + [(0, "full (again)")]:          # (the first timing of a weight set runs 5-15 % slow: clocks)
+            for abl, nm in list(names.items()) + [(0, "full (again)")] + [(-1 - v, "dbg %d" % v) for v in dbgs]:          # (the first timing of a weight set runs 5-15 % slow: clocks)
                 d = _ffi.ev_conv_gemm_desc()
                 h, q, s = xi
                 d.dtype, d.A, d.lda, d.W, d.W_lo, d.W_mx = 3, h[PAD:].data_ptr(), Cc, d_hi.data_ptr(), d_hi.data_ptr(), d_mx.data_ptr()
@@ -68,7 +70,7 @@ def main():
                     d.act, d.act_slope = 3, 0.1
                 else:
                     d.res, d.res_dtype, d.ldres, d.out32 = res.data_ptr(), 1, Cc, out.data_ptr()
-                d.reserved0 = abl << 4
+                d.reserved0 = (abl << 4) if abl >= 0 else (-1 - abl)
                 for _ in range(6):
                     rc = lib.ev_op_conv_gemm(C.byref(d), None)
                     assert rc == 0, rc

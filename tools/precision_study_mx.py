@@ -62,8 +62,13 @@ def mx_quant(v, fmt, dim):
 
 
 class Recipe:
-    def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None):
+    def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None, mrf16=False,
+                 engine_flow=False):
         self.name, self.cross, self.res32, self.op32, self.lo_terms = name, cross, res32, op32, lo_terms
+        # mrf16: the first two scaled ResBlock outputs of a stage are stored in fp16 and added in the third one's fp32 epilogue (the fast mode's MRF sum:
+        # 8 bytes less HBM traffic per stage-output element than an fp32 running sum)
+        # engine_flow: the engine's actual data flow -- stage 3 (C = 32) keeps fp32 in / out (fused pairs), conv_pre's output is fp32 (planes are cut from it)
+        self.mrf16, self.engine_flow = mrf16, engine_flow
         # res_planes: the residual stream exists ONLY as the plane set of leaky_relu(x, .1) its consumers read anyway: fp16 hi plane + the
         # remainder in this format ("f16" = a second fp16 plane, "fp4" / "fp6" = the MX code plane itself); None = a separate fp32 tensor
         self.res_planes = res_planes
@@ -111,7 +116,10 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
     x = mel_ct.unsqueeze(0)
     x = st(conv(x, prefix + ".conv_pre", padding=3))
     nk = len(shapes.rb_kernels)
+    st_planes = st
     for i, (u, k) in enumerate(zip(shapes.up_rates, shapes.up_kernels)):
+        if rc.engine_flow and rc.res_planes:
+            st = st_planes if i + 1 < len(shapes.up_rates) else (lambda t: t)
         x = F.leaky_relu(x, 0.1)
         x = conv_mx(x, fold_weight_norm(sd, f"{prefix}.ups.{i}"), sd[f"{prefix}.ups.{i}.bias"], rc, transposed=True,
                     stride=u, padding=(k - u) // 2)
@@ -126,6 +134,8 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
                 xt = conv(xt, f"{r}.convs2.{d_i}", dilation=1, padding=(rk - 1) // 2)
                 y = st(xt + y)
             y = y / nk
+            if rc.mrf16 and j + 1 < nk:
+                y = r16(y)
             xs = y if xs is None else xs + y
         x = st(xs)
     x = F.leaky_relu(x)
@@ -144,16 +154,19 @@ def main():
     ap.add_argument("--phonemes", type=int, default=48)
     ap.add_argument("--seed", type=int, default=21)
     ap.add_argument("--mel16", action="store_true", help="round the generator's mel input to fp16 first")
+    ap.add_argument("--weights", default="parity", help="synthetic weight recipe: parity (conv_post bias re-centred here for a zero-mean waveform) or "
+                                                        "parity_zdc_hot (trained-like gains, the worst reference fixture's recipe)")
+    ap.add_argument("--only", default=None, help="substring filter on the recipe names")
     args = ap.parse_args()
     torch.set_num_threads(8)
     shapes = EVShapes()
-    sd = to_torch_sd(synth_state_dict(0, "parity"))
+    sd = to_torch_sd(synth_state_dict(0, args.weights))
     utt = synth_inputs(args.seed, [args.phonemes], [7])[0]
     with torch.no_grad():
         am = am_forward(sd, torch.from_numpy(utt["ling"]), 7, torch.from_numpy(utt["style"]), torch.from_numpy(utt["content"]), shapes)
         mel = am["dec_outputs"].t().contiguous()
         lo, hi = -20.0, 20.0
-        for _ in range(30):
+        for _ in range(0 if "zdc" in args.weights else 30):
             mid = 0.5 * (lo + hi)
             sd["generator.conv_post.bias"] = torch.tensor([mid])
             if hifigan_forward(sd, mel, shapes).mean().item() > 0:
@@ -174,11 +187,16 @@ def main():
             Recipe("+ MX-fp4 cross terms, residual = hi plane + fp16 remainder plane", "fp4", res_planes="f16"),
             Recipe("+ MX-fp4 cross terms, residual = hi plane + fp6 remainder codes", "fp4", res_planes="fp6"),
             Recipe("+ MX-fp4 cross terms, residual = hi plane + fp4 remainder codes", "fp4", res_planes="fp4"),
+            Recipe("ENGINE r4: MX-fp4, residual from fp4 planes (stages 0-2), fp32 stage 3", "fp4", res_planes="fp4", engine_flow=True),
+            Recipe("ENGINE r4 + fp16 MRF partial sums", "fp4", res_planes="fp4", engine_flow=True, mrf16=True),
+            Recipe("MX-fp4, fp32 residual + fp16 MRF partial sums", "fp4", mrf16=True),
             Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
             Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
         ]
         m_in = r16(mel) if args.mel16 else mel
         for rc in cases:
+            if args.only and args.only not in rc.name:
+                continue
             out = emulate(sd, m_in, shapes, rc)
             e, eac = errs(out, ref)
             print("%-52s wav %.3e   wav_ac %.3e" % (rc.name, e, eac), flush=True)
