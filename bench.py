@@ -207,6 +207,7 @@ VOC_FAMILIES = {
     "voc_conv_gemm_x3": (3.0, "conv_gemm_x3_kernel / conv_gemm_split_kernel: three fp16 MFMAs per product"),
     "voc_conv_gemm_mx": (1.5, "conv_gemm_mx_kernel: one fp16 MFMA + two block-scaled fp4 MFMAs (4x rate) per product, operand planes from the producer's epilogue"),
     "voc_conv_c64_mx": (1.5, "conv_c64_mx_kernel (stage 2, C = 64: two taps per fp4 MFMA, plane sets in / out)"),
+    "voc_resblock_pair_c64_mx": (1.5, "resblock_pair_c64_mx_kernel (fused k = 3 pair of stage 2, plane sets in / out, xt and the residual never cross HBM)"),
     "voc_resblock_pair_c32_mx": (1.5, "resblock_pair_c32_mx_kernel (fused pair, fp16 + fp4 MFMAs, fp32 in / out)"),
 }
 DOMINANT = {"f16": "voc_conv_gemm_f16", "x3": "voc_conv_gemm_x3", "mx": "voc_conv_gemm_mx"}

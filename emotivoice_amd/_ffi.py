@@ -111,6 +111,7 @@ SIGNATURES = {
     "ev_op_resblock_pair_c32": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_resblock_pair_c64": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_resblock_pair_c32_mx": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
+    "ev_op_resblock_pair_c64_mx": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_layernorm": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_float, _P, _P]),
     "ev_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
 }

@@ -638,7 +638,10 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                                       c.fused_pairs == 0;
                 // the plane set of lrelu(x, .1) this pair starts from: conv1's operand and, with rpl, conv2's residual
                 const PlaneBuf& xin = d == 0 ? vb.pl_xu : ((d - 1) % 2 == 0 ? vb.pl_a : vb.pl_b);
-                if (fused_mx) {
+                // EV_PREC_MX at C = 64, k = 3 with the residual in the planes: the pair in one persistent kernel (ev_pair64_mx.h), plane sets in / out -- xt never
+                // reaches HBM and the residual comes from the slab conv1 reads (6.1 instead of 14.8 bytes per element; the k = 3 chain of stage 2 is HBM-bound)
+                const bool fused_c64 = stage_mx && rpl && cout == 64 && k == 3 && dil <= 8 && c.fused_pairs == 0 && has_wt(c1 + ".wcmx") && has_wt(c2 + ".wcmx");
+                if (fused_mx || fused_c64) {
                 } else if (stage_mx) {
                     // MX stage: xt only ever exists as conv2's operand planes; x travels as fp32 (the residual) + the planes of lrelu(x); with EV_MX_RESPL=1 as the planes only
                     p = gemm_defaults();
@@ -710,7 +713,19 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     (void)hipStreamWaitEvent(h->stream, h->ev_join[0], 0);
                     (void)hipStreamWaitEvent(h->stream, h->ev_join[1], 0);
                 }
-                if (fused_mx) {
+                if (fused_c64) {
+                    WPTR(w1, char, c1 + ".w16"); WPTR(b1, float, c1 + ".b"); WPTR(w1m, char, c1 + ".wcmx");
+                    const MxView xv = mx_view(xin, (size_t)rows_out, cout);
+                    ResPairParams rp;
+                    memset(&rp, 0, sizeof rp);
+                    rp.x = xv.h; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = p.W; rp.w1_mx = w1m; rp.w2_mx = p.W_mx;
+                    rp.M = p.M; rp.k = k; rp.dil = dil; rp.epi = p;
+                    rp.epi.mx_x4[0] = xv.q4[0]; rp.epi.mx_x4[1] = xv.q4[1]; rp.epi.mx_xs[0] = xv.qs[0]; rp.epi.mx_xs[1] = xv.qs[1]; rp.epi.mx_xs_stride = xv.qs_stride;
+                    const double fl = 2.0 * 2.0 * valid_out * cout * (double)cout * k;
+                    ConvGemmParams shape = p; shape.dil = dil;
+                    KScope ks(h, "voc_resblock_pair_c64_mx", fl, valid_out * cout * 3.0625 * 2.0, sj, &shape);
+                    if (launch_resblock_pair_c64_mx(rp, sj)) return fail(h, "fused MX pair (C = 64): unsupported call (k %d, dil %d)", k, dil);
+                } else if (fused_mx) {
                     WPTR(w1, char, c1 + ".w16"); WPTR(b1, float, c1 + ".b"); WPTR(w1m, char, c1 + ".wpmx"); WPTR(w2m, char, c2 + ".wpmx");
                     ResPairParams rp;
                     memset(&rp, 0, sizeof rp);
@@ -1552,6 +1567,12 @@ int ev_op_resblock_pair_c32_mx(const ev_res_pair_desc* d, void* stream) {
     memcpy(&p, d, sizeof p);
     if (p.M <= 0 || p.dil < 1 || (p.k - 1) * p.dil > 64) return -2;
     if (launch_resblock_pair_c32_mx(p, (hipStream_t)stream)) return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int ev_op_resblock_pair_c64_mx(const ev_res_pair_desc* d, void* stream) {
+    ResPairParams p;
+    memcpy(&p, d, sizeof p);
+    if (launch_resblock_pair_c64_mx(p, (hipStream_t)stream)) return -2;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int ev_op_resblock_pair_c64(const ev_res_pair_desc* d, void* stream) {

@@ -487,7 +487,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += bias2[j];
             if constexpr (EPI & EPI_RARE_ACT) {
-                if (act == ACT_GELU && (EPI & EPI_O16)) {          // the A&S erf only where the result is rounded to fp16
+                if (act == ACT_GELU && (EPI & (EPI_O16 | EPI_MXP)) && !(EPI & EPI_O32)) {          // the A&S erf (|error| <= 1.5e-7) only where the result is rounded
+                                                                                                    // to fp16 or to an MX plane set (fp16 hi + fp4 remainder: ~2^-14)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j][0] = gelu_fast(v[j][0]); v[j][1] = gelu_fast(v[j][1]); }
                 } else {
@@ -2352,6 +2353,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
 #include "ev_pair_mx.h"
 
 #include "ev_conv64_mx.h"
+#include "ev_pair64_mx.h"
 
 int init_device_kernels(int device) {
     if (device < 0 || device >= 64) return -1;
@@ -2374,6 +2376,7 @@ int init_device_kernels(int device) {
     if (mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (pair_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (conv64_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
+    if (pair64_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     g_dev_ready[device] = (e == hipSuccess);
     return e == hipSuccess ? 0 : -1;
 }

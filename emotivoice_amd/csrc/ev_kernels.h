@@ -98,6 +98,10 @@ void launch_resblock_pair_c32(const ResPairParams& p, hipStream_t s);
 // the same pair in the MX arithmetic (ev_pair_mx.h): x / epi.res fp32 [rows][32], w1 / w2 the fp16 hi parts, w1_mx / w2_mx the fp4 planes;
 // epilogue: bias, fp32 residual (= x), out_scale, optional acc32, row mask, out32 only.  Returns 0, or -1 for an unsupported call.
 int launch_resblock_pair_c32_mx(const ResPairParams& p, hipStream_t s);
+// the pair at C = 64, k = 3 in the MX arithmetic, plane sets in / out (ev_pair64_mx.h): x = the fp16 hi plane of the input plane set (ldx == 64), epi.mx_x4 /
+// mx_xs its code / scale planes, w1 / w2 fp16 hi parts, w1_mx / w2_mx = mxfp4.pack_c64_weight_planes; the residual is rebuilt from the input plane set
+// (epi.res_inv_slope); outputs epi.out32 and / or the plane set epi.mxo_*.  Returns 0, or -1 for an unsupported call.
+int launch_resblock_pair_c64_mx(const ResPairParams& p, hipStream_t s);
 // same pair at C = 64 (stage 2), k = 3 only: both weight sets (48 KB) stationary in LDS, x as two 64-byte K-chunk planes
 void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s);
 

@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void attention_mfma_f32_kernel(const AttnParam
 // plain register packs.  Per 16-key tile: 9 + 9 fp16 MFMAs at the 16x rate instead of 12 + 12 fp32 ones; the exact-fp32 kernel stays for the
 // token-rate encoder (its output decides the bit-exact durations) and SimBERT.
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split4(const float* x, h4& hi, h4& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -724,6 +725,12 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_x3_lds_kernel(const At
             split4(x, qh[c], ql[c]);
         }
     }
+    // d_k = 48 as TWO K = 32 MFMAs per product term, the second one half zeros (the lane's slots 8..11 + four zeros).  Not a 16x16x32 + a legacy 16x16x16
+    // on the same accumulator: that mix measured 5e-5 ... 4e-4 and run-to-run differences on the MI355X (a dependent chain across the two opcodes
+    // loses cross terms; the legacy form issues at the K = 32 form's 16 cycles anyway, so the zero half costs nothing).
+    const h4 z4 = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    const h8 qh8 = __builtin_shufflevector(qh[0], qh[1], 0, 1, 2, 3, 4, 5, 6, 7), ql8 = __builtin_shufflevector(ql[0], ql[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    const h8 qh8b = __builtin_shufflevector(qh[2], z4, 0, 1, 2, 3, 4, 5, 6, 7), ql8b = __builtin_shufflevector(ql[2], z4, 0, 1, 2, 3, 4, 5, 6, 7);
     // staging roles: unit u = tid + NT j (768 units per stage); u < 384: K unit (key u / 12, float4 u % 12), else V unit u - 384
     int ukey[NJ], uc4[NJ];
     bool uv[NJ], uon[NJ];
@@ -767,45 +774,63 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_x3_lds_kernel(const At
     for (int sg = 0; sg < nstage; ++sg) {
         if (sg + 1 < nstage) EV_ATL_LOAD(sg + 1)
         const char* sb = lds + (sg & 1) * STAGE;
+        // Round 4: the stage's 32 keys as ONE softmax step on the double-K MFMAs.  d_k = 48 is two v_mfma_f32_16x16x32_f16 (slots 0..7 of the lane's 12, then
+        // slots 8..11 + zeros) per product term instead of three 16x16x16 -- the legacy K = 16 form issues at the K = 32 form's 16 cycles on gfx950 --,
+        // and P.V reduces over all 32 keys in one K = 32 MFMA per (output tile, term): k-slot j of lane group g is key 4 g + j of the first 16-key tile
+        // (j < 4) or of the second (j >= 4), which is how the two S^T tiles leave their accumulators, so P still never moves.  36 -> 21 MFMAs per 32 keys
+        // and one running-max / rescale pass instead of two.  Keys beyond the utterance (second half of the last stage) get score -inf -> weight 0; their
+        // K / V rows are clamped copies of the last key (finite).
+        {
+            const int kbase = sg * KT;
+            f4 sh[2], sx[2];
 #pragma unroll
-        for (int half = 0; half < KT / 16; ++half) {
-            const int kbase = sg * KT + half * 16;
-            if (kbase >= len) break;                              // (uniform: the stage's second 16 keys may lie beyond the utterance)
-            f4 sh = f4{0.f, 0.f, 0.f, 0.f}, sx = f4{0.f, 0.f, 0.f, 0.f};
-            const char* kp = sb + (half * 16 + fr) * KP + g * 24;
-#pragma unroll
-            for (int c = 0; c < NS; ++c) {
-                const h4 kh = *reinterpret_cast<const h4*>(kp + c * 8), kl = *reinterpret_cast<const h4*>(kp + KB + c * 8);
-                sh = __builtin_amdgcn_mfma_f32_16x16x16f16(kh, qh[c], sh, 0, 0, 0);
-                sx = __builtin_amdgcn_mfma_f32_16x16x16f16(kh, ql[c], sx, 0, 0, 0);
-                sx = __builtin_amdgcn_mfma_f32_16x16x16f16(kl, qh[c], sx, 0, 0, 0);
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const char* kp = sb + (hlf * 16 + fr) * KP + g * 24;
+                const h4 k0h = *reinterpret_cast<const h4*>(kp), k1h = *reinterpret_cast<const h4*>(kp + 8), k2h = *reinterpret_cast<const h4*>(kp + 16);
+                const h4 k0l = *reinterpret_cast<const h4*>(kp + KB), k1l = *reinterpret_cast<const h4*>(kp + KB + 8), k2l = *reinterpret_cast<const h4*>(kp + KB + 16);
+                const h8 kh8 = __builtin_shufflevector(k0h, k1h, 0, 1, 2, 3, 4, 5, 6, 7), kl8 = __builtin_shufflevector(k0l, k1l, 0, 1, 2, 3, 4, 5, 6, 7);
+                const h8 kh8b = __builtin_shufflevector(k2h, z4, 0, 1, 2, 3, 4, 5, 6, 7), kl8b = __builtin_shufflevector(k2l, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+                f4 a = f4{0.f, 0.f, 0.f, 0.f}, x = f4{0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh8, qh8, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh8b, qh8b, a, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh8, ql8, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh8b, ql8b, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl8, qh8, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl8b, qh8b, x, 0, 0, 0);
+                sh[hlf] = a; sx[hlf] = x;
             }
-            float sc[4];
+            float sc[8];
             float cm = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sc[i] = (kbase + 4 * g + i < len) ? sh[i] + sx[i] * LO : -INFINITY;
-                cm = fmaxf(cm, sc[i]);
-            }
+            for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sc[hlf * 4 + i] = (kbase + hlf * 16 + 4 * g + i < len) ? sh[hlf][i] + sx[hlf][i] * LO : -INFINITY;
+                    cm = fmaxf(cm, sc[hlf * 4 + i]);
+                }
             cm = rows_max(cm);
             const float mn = fmaxf(m, cm);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);            // (m = -inf on the first tile -> 0)
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);            // (m = -inf on the first stage -> 0)
             m = mn;
-            float pr[4];
+            float pr[8];
             float ps = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { pr[i] = __builtin_amdgcn_exp2f(sc[i] - mn); ps += pr[i]; }
+            for (int i = 0; i < 8; ++i) { pr[i] = __builtin_amdgcn_exp2f(sc[i] - mn); ps += pr[i]; }
             l = l * alpha + ps;
-            h4 ph, pl;
-            split4(pr, ph, pl);
-            const char* vp = sb + 2 * KB + fr * VP + (half * 16 + 4 * g) * 2;
+            h4 p0h, p0l, p1h, p1l;
+            split4(pr, p0h, p0l);
+            split4(pr + 4, p1h, p1l);
+            const h8 ph8 = __builtin_shufflevector(p0h, p1h, 0, 1, 2, 3, 4, 5, 6, 7), pl8 = __builtin_shufflevector(p0l, p1l, 0, 1, 2, 3, 4, 5, 6, 7);
+            const char* vp = sb + 2 * KB + fr * VP + (4 * g) * 2;
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt) {
-                const h4 vh = *reinterpret_cast<const h4*>(vp + dt * 16 * VP), vl = *reinterpret_cast<const h4*>(vp + VB + dt * 16 * VP);
+                const h4 v0h = *reinterpret_cast<const h4*>(vp + dt * 16 * VP), v1h = *reinterpret_cast<const h4*>(vp + dt * 16 * VP + 32);
+                const h4 v0l = *reinterpret_cast<const h4*>(vp + VB + dt * 16 * VP), v1l = *reinterpret_cast<const h4*>(vp + VB + dt * 16 * VP + 32);
+                const h8 vh8 = __builtin_shufflevector(v0h, v1h, 0, 1, 2, 3, 4, 5, 6, 7), vl8 = __builtin_shufflevector(v0l, v1l, 0, 1, 2, 3, 4, 5, 6, 7);
                 oh[dt] *= alpha; ox[dt] *= alpha;
-                oh[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, ph, oh[dt], 0, 0, 0);
-                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, pl, ox[dt], 0, 0, 0);
-                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vl, ph, ox[dt], 0, 0, 0);
+                oh[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh8, ph8, oh[dt], 0, 0, 0);
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh8, pl8, ox[dt], 0, 0, 0);
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl8, ph8, ox[dt], 0, 0, 0);
             }
         }
         if (sg + 1 < nstage) EV_ATL_STORE((sg + 1) & 1)        // (the other buffer: its last readers finished before the previous barrier)

