@@ -494,8 +494,16 @@ struct VocBufs {
     Buf pre, xu[4], tmp[3], rba[3], rbb[3], nxt[4], mrf32, mrf16a, mrf16b, wavrows; Buf mrf_tap[4]; Buf pre_tap;
     // EV_PREC_MX: plane sets of the up-conv output, conv1's output, the two alternating ResBlock states and the stage output; the
     // planes-kernel scratch of the one fp32 tensor an MX launch reads (conv_pre's output)
-    PlaneBuf pl_xu, pl_t, pl_a, pl_b, pl_nxt; char* mx_scratch = nullptr; size_t mx_scratch_bytes = 0;
+    // (pl_t / pl_a / pl_b: one set per ResBlock of a stage when the three run concurrently -- small batches, voc_small_batch -- else only [0])
+    PlaneBuf pl_xu, pl_t[3], pl_a[3], pl_b[3], pl_nxt; char* mx_scratch = nullptr; size_t mx_scratch_bytes = 0;
 };
+
+// Small batches (single utterances: the reference's own call pattern): a generator launch is a handful of tiles whose K loops are sequential chains
+// (tools/probe_b1.py: 39 conv launches of ~35 us each for 64 phonemes while 240 of 256 CUs idle), so the three ResBlocks of a stage -- independent until
+// their scaled outputs meet in the MRF sum -- run on three streams there, also in the mx mode (each with its own intermediates; the running fp32 sum
+// keeps its order rb0, rb1, rb2 through events, so the result has the same bits as the serial order).  At full batches a launch fills the chip and
+// streams only reorder the same work (measured in round 3: 54.99 vs 54.56 ms), so large batches stay serial and allocate one set of intermediates.
+static bool voc_small_batch(int Rf) { return Rf <= 2048; }
 
 // weights of one generator conv: fp16 (also the "hi" part of the split) and, in the split-precision mode, the "lo" part
 int voc_weights(ev_handle* h, const std::string& base /* e.g. "voc.rb3.c1.0" */, bool x3, ConvGemmParams& p, bool mx = false) {
@@ -613,7 +621,8 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         // MFMA-bound, so their workgroups complement each other on a CU and fill each other's launch tails.  Profiled steps
         // (per-launch events) and chunked execution stay on one stream.  (Split-precision mode: the MRF sum is a running fp32
         // accumulator shared by the three ResBlocks, so they run in order on the handle's stream.)
-        const bool conc = c.n_rb == 3 && nchunks == 1 && !x3 && !h->profiling && c.vocoder_streams != 1 && h->aux[0] && h->aux[1];
+        const bool conc = c.n_rb == 3 && nchunks == 1 && (!x3 || (mx && !keep && voc_small_batch(Rf))) && !h->profiling && c.vocoder_streams != 1 &&
+                          h->aux[0] && h->aux[1];
         if (conc) {
             (void)hipEventRecord(h->ev_fork, h->stream);
             (void)hipStreamWaitEvent(h->aux[0], h->ev_fork, 0);
@@ -637,7 +646,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                 const bool fused_mx = mx && cout == 32 && (k == 3 || k == 7 || k == 11) && (k - 1) * (dil + 1) <= 64 && has_wt(c1 + ".wpmx") && has_wt(c2 + ".wpmx") &&
                                       c.fused_pairs == 0;
                 // the plane set of lrelu(x, .1) this pair starts from: conv1's operand and, with rpl, conv2's residual
-                const PlaneBuf& xin = d == 0 ? vb.pl_xu : ((d - 1) % 2 == 0 ? vb.pl_a : vb.pl_b);
+                const PlaneBuf& xin = d == 0 ? vb.pl_xu : ((d - 1) % 2 == 0 ? vb.pl_a[bj] : vb.pl_b[bj]);
                 // EV_PREC_MX at C = 64, k = 3 with the residual in the planes: the pair in one persistent kernel (ev_pair64_mx.h), plane sets in / out -- xt never
                 // reaches HBM and the residual comes from the slab conv1 reads (6.1 instead of 14.8 bytes per element; the k = 3 chain of stage 2 is HBM-bound)
                 const bool fused_c64 = stage_mx && rpl && cout == 64 && k == 3 && dil <= 8 && c.fused_pairs == 0 && has_wt(c1 + ".wcmx") && has_wt(c2 + ".wcmx");
@@ -649,7 +658,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     mx_in(p, mx_view(xin, (size_t)rows_out, cout), cout);
                     p.M = rows_out; p.N = cout; p.K = cout; p.taps = k; p.dil = dil; p.center = (k - 1) / 2;
                     p.row_valid = h->d_frm_valid; p.valid_shift = shift; p.act = ACT_LRELU; p.act_slope = 0.1f; p.ldo = cout;
-                    mx_out(p, mx_view(vb.pl_t, (size_t)rows_out, cout), 1.0f);
+                    mx_out(p, mx_view(vb.pl_t[bj], (size_t)rows_out, cout), 1.0f);
                     if (gemm(h, cout == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx", p, valid_out, sj)) return -1;
                 } else if (!fused) {
                     // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
@@ -668,7 +677,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                 p.A = vb.tmp[bj].p; p.lda = cout; p.M = rows_out; p.N = cout; p.K = cout;
                 if (stage_mx) {
                     if (p.dtype != DT_MX) return fail(h, "MX stage: %s has no fp4 planes", c2.c_str());
-                    mx_in(p, mx_view(vb.pl_t, (size_t)rows_out, cout), cout);
+                    mx_in(p, mx_view(vb.pl_t[bj], (size_t)rows_out, cout), cout);
                 }
                 p.taps = k; p.dil = 1; p.center = (k - 1) / 2; p.row_valid = h->d_frm_valid; p.valid_shift = shift;
                 p.res = xcur; p.res_dtype = x3 ? DT_F32 : DT_F16; p.ldres = cout; p.ldo = cout;
@@ -680,7 +689,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     void* dst = (d % 2 == 0) ? vb.rba[bj].p : vb.rbb[bj].p;
                     if (!rpl || keep) set_out(p, dst);          // (rpl: the next pair reads the planes below; the fp32 copy only feeds stage taps)
                     xcur = dst;
-                    if (stage_mx) mx_out(p, mx_view(d % 2 == 0 ? vb.pl_a : vb.pl_b, (size_t)rows_out, cout), 0.1f);     // the next conv1's operand
+                    if (stage_mx) mx_out(p, mx_view(d % 2 == 0 ? vb.pl_a[bj] : vb.pl_b[bj], (size_t)rows_out, cout), 0.1f);     // the next conv1's operand
                 } else {
                     // MRF: xs += resblock(x); x = xs / num_kernels (models.py:121-126), then the next leaky_relu
                     // fp16 mode with three ResBlocks (the reference config): the first two scaled branches are kept in fp16 and the
@@ -713,6 +722,8 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     (void)hipStreamWaitEvent(h->stream, h->ev_join[0], 0);
                     (void)hipStreamWaitEvent(h->stream, h->ev_join[1], 0);
                 }
+                // fp32 running sum (split-precision / mx modes): rb1's last conv adds onto what rb0's wrote (the sum keeps the serial order's bits)
+                if (conc && x3 && j == 1 && d + 1 == c.n_rb_dils) (void)hipStreamWaitEvent(h->aux[1], h->ev_join[0], 0);
                 if (fused_c64) {
                     WPTR(w1, char, c1 + ".w16"); WPTR(b1, float, c1 + ".b"); WPTR(w1m, char, c1 + ".wcmx");
                     const MxView xv = mx_view(xin, (size_t)rows_out, cout);
@@ -796,9 +807,10 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
         shared_xu = mk2(ves); shared_nxt[0] = mk2(ves); shared_nxt[1] = mk2(ves);
         for (int i = 0; i < c.n_up; ++i) { vb.xu[i] = shared_xu; vb.nxt[i] = shared_nxt[i & 1]; }
     }
-    const bool per_rb = (c.n_rb == 3) && !x3;      // fp16 mode: the three ResBlocks of a stage run concurrently, each with its own intermediates
+    // fp16 mode, and small batches in the mx mode: the three ResBlocks of a stage run concurrently, each with its own intermediates
+    const bool per_rb = (c.n_rb == 3) && (!x3 || (mx && !keep && voc_small_batch(Rf)));
     for (int j = 0; j < (per_rb ? 3 : 1); ++j) { vb.tmp[j] = mk2(ves); vb.rba[j] = mk2(ves); vb.rbb[j] = mk2(ves); }
-    if (per_rb) { vb.mrf16a = mk2(2); vb.mrf16b = mk2(2); } else vb.mrf32 = mk2(4);
+    if (per_rb && !x3) { vb.mrf16a = mk2(2); vb.mrf16b = mk2(2); } else vb.mrf32 = mk2(4);
     vb.wavrows = ap.rows((size_t)Rf * total_up(c), 1, 4);
     if (mx) {
         // plane sets, re-used across the stages that run on the MX kernel (C % 128 == 0): sized by the largest
@@ -810,7 +822,8 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
             const size_t R = (size_t)Rf * U + 2 * MX_PAD;
             hb = std::max(hb, R * ch * 2); qb = std::max(qb, R * (ch / 2)); sb = std::max(sb, (size_t)std::max(1, ch / 128) * R * 4);
         }
-        PlaneBuf* sets[5] = {&vb.pl_xu, &vb.pl_t, &vb.pl_a, &vb.pl_b, &vb.pl_nxt};
+        std::vector<PlaneBuf*> sets = {&vb.pl_xu, &vb.pl_nxt};
+        for (int j = 0; j < (per_rb ? 3 : 1); ++j) { sets.push_back(&vb.pl_t[j]); sets.push_back(&vb.pl_a[j]); sets.push_back(&vb.pl_b[j]); }
         for (PlaneBuf* b : sets) {
             if (!hb) break;
             b->h = ap.take(hb);
