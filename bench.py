@@ -54,6 +54,9 @@ def mx_contract_bytes_per_frame(residual_from_planes=True):
             continue
         b += Ein[s] * P + e * P + (0 if residual_from_planes else 4 * e)
         for j in range(3):
+            if s == 2 and j == 0 and residual_from_planes:            # the k = 3 ResBlock of stage 2: fused pairs (ev_pair64_mx.h), planes in / planes (or the fp32 MRF sum) out
+                b += 2 * (e * P + e * P) + e * P + 4 * e
+                continue
             for d in range(3):
                 res = e * R if residual_from_planes else 4 * e
                 b += 2 * e * P + e * P + res                              # conv1 in / out, conv2 xt in + residual
@@ -64,8 +67,8 @@ def mx_contract_bytes_per_frame(residual_from_planes=True):
     return b + E[3] * 4 + 256 * 4                                    # conv_post
 
 
-# per-mode layer-wise contracts of the modes' own data flows (fp16: SURVEY 8(d); split precision: fp32 tensors; mx: 3.550 MB with the residual
-# rebuilt from planes -- the default since round 4 --, 4.310 MB with a separate fp32 residual tensor)
+# per-mode layer-wise contracts of the modes' own data flows (fp16: SURVEY 8(d); split precision: fp32 tensors; mx: 3.336 MB with the residual
+# rebuilt from planes and the fused k = 3 pairs of stage 2 -- the default since round 4 --, 4.310 MB with a separate fp32 residual tensor)
 VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": mx_contract_bytes_per_frame(True)}
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
@@ -312,7 +315,7 @@ def roofline_block(eng, work, torch, dump=None):
                                            hbm_contract_frac=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
                                            hbm_contract_bytes_per_frame=VOC_BYTES_PER_FRAME_BY_MODE[mode],
                                            hbm_contract_note="this mode's layer-wise byte contract (fp16: 2.026 MB / frame; split precision: fp32 tensors, 2x; "
-                                                             "mx: plane sets, residuals rebuilt from them, fp32 running MRF sums, 3.55 MB / frame)"))
+                                                             "mx: plane sets, residuals rebuilt from them, fp32 running MRF sums, fused k = 3 pairs at C = 64: 3.34 MB / frame)"))
         if voc_pmc:
             roof["all_vocoder_convs"].update(hbm_pmc_bytes_per_frame=round(voc_pmc, 1), hbm_pmc_GBps=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9, 1),
                                              hbm_pmc_frac=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),

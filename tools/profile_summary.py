@@ -48,15 +48,19 @@ FAMILIES = {
     # (the fp16 family = the 4-wave kernel + the phased 8-wave kernel that takes its MFMA-bound shapes)
     "conv_gemm_f16_vocoder": lambda f: [r for r in f if _is_f16_gemm(r["Kernel_Name"])][N_DEC:],
     "conv_gemm_f16_decoder": lambda f: [r for r in f if _is_f16_gemm(r["Kernel_Name"])][:N_DEC],
-    "resblock_pair_c32_c64": lambda f: [r for r in f if "resblock_pair_c" in r["Kernel_Name"]],
+    "resblock_pair_c32_c64": lambda f: [r for r in f if "resblock_pair_c32_kernel" in r["Kernel_Name"] or "resblock_pair_c64_kernel" in r["Kernel_Name"]],
     "attention_mfma_f16": lambda f: [r for r in f if "attention_mfma_kernel" in r["Kernel_Name"]],
     "conv_gemm_split_token_rate": lambda f: [r for r in f if "conv_gemm_split_kernel" in r["Kernel_Name"] or "conv_gemm_x3_kernel" in r["Kernel_Name"]],
     "layernorm": lambda f: [r for r in f if "layernorm_kernel" in r["Kernel_Name"]],
     # round 3, "mx" precision (bench.py's default): the generator's three MX kernels, the decoder's conv-FFN on the same conv-GEMM kernel
     "conv_gemm_mx_vocoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][N_DEC_MX:],
     "conv_gemm_mx_decoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][:N_DEC_MX],
-    "conv_c64_mx": lambda f: [r for r in f if "conv_c64_mx_kernel" in r["Kernel_Name"]],
-    "resblock_pair_c32_mx": lambda f: [r for r in f if "resblock_pair_c32_mx_kernel" in r["Kernel_Name"]],
+    # (round 4: the two-group variants conv_c64_mx2_kernel / resblock_pair_c32_mx2_kernel are the launchers' default; the fused C = 64 / k = 3 pair)
+    "conv_c64_mx": lambda f: [r for r in f if "conv_c64_mx" in r["Kernel_Name"]],
+    "resblock_pair_c64_mx": lambda f: [r for r in f if "resblock_pair_c64_mx" in r["Kernel_Name"]],
+    "resblock_pair_c32_mx": lambda f: [r for r in f if "resblock_pair_c32_mx" in r["Kernel_Name"]],
+    "attention_mfma_x3_lds": lambda f: [r for r in f if "attention_mfma_x3_lds_kernel" in r["Kernel_Name"]],
+    "conv_post": lambda f: [r for r in f if "conv_post" in r["Kernel_Name"]],
     "mx_planes_kernel": lambda f: [r for r in f if "mx_planes_kernel" in r["Kernel_Name"]],
     "attention_mfma_f32": lambda f: [r for r in f if "attention_mfma_f32_kernel" in r["Kernel_Name"]],
 }
@@ -148,7 +152,7 @@ def main():
                              hbm_bytes_per_forward=fb + wb, hbm_bytes_per_launch=(fb + wb) / ff[name]["launches"])
         frames = 32768
         voc = sum(fam[k]["hbm_bytes_per_forward"] for k in ("conv_gemm_f16_vocoder", "resblock_pair_c32_c64", "conv_gemm_mx_vocoder", "conv_c64_mx",
-                                                            "resblock_pair_c32_mx", "mx_planes_kernel") if k in fam)
+                                                            "resblock_pair_c64_mx", "resblock_pair_c32_mx", "mx_planes_kernel") if k in fam)
         dom = "conv_gemm_mx_vocoder" if args.mode == "mx" else "conv_gemm_f16_vocoder"
         doc = {
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 1 --warmup 1 --cpu-utts 0 --no-other-precision`, the B=32 x 1024-frame forward",
