@@ -407,7 +407,10 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         p.row_valid = rc.valid; p.ldo = 3 * C;
         if (prec == DT_F32 && tok_weights(h, lp + ".qkv.w", p)) return -1;
         if (prec == DT_F16) p.out16 = qkv.p; else p.out32 = (float*)qkv.p;
-        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        // EV_PREC_MX decoder: the QKV / output projections on the one-tap MX GEMM (ev_gemm_mx1.h); their fp32 inputs become plane sets in the scratch
+        const bool lin_mx = dmx && p.dtype == DT_F32S && h->wt.count(lp + ".qkv.wmx") && h->wt.count(lp + ".out.wmx");
+        if (lin_mx) { p.dtype = DT_MX; p.W_mx = h->wt[lp + ".qkv.wmx"].ptr; p.mx_scratch = dmx->scratch; p.mx_scratch_size = dmx->scratch_bytes; }
+        if (gemm(h, lin_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         AttnParams ap{};
         // decoder in the strict / mx modes: split-precision attention (three fp16 MFMAs per product); the token-rate encoder keeps exact fp32
         const bool att_split = prec == DT_F32 && !strcmp(pre, "dec") && (h->cfg.decoder_precision == EV_PREC_X3 || h->cfg.decoder_precision == EV_PREC_MX) &&
@@ -419,7 +422,8 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         p.dtype = prec; p.A = ctx.p; p.lda = C; p.W = wout; p.bias = bout; p.M = rc.R; p.N = C; p.K = C;
         p.row_valid = rc.valid; p.res = x.p; p.res_dtype = DT_F32; p.ldres = C; p.out32 = (float*)x.p; p.ldo = C;
         if (prec == DT_F32 && tok_weights(h, lp + ".out.w", p)) return -1;
-        if (gemm(h, (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
+        if (lin_mx) { p.dtype = DT_MX; p.W_mx = h->wt[lp + ".out.wmx"].ptr; p.mx_scratch = dmx->scratch; p.mx_scratch_size = dmx->scratch_bytes; }
+        if (gemm(h, lin_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         ln.gamma = g2; ln.beta = b2;
         { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
         p = gemm_defaults();

@@ -340,6 +340,8 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     }
 }
 
+#include "ev_gemm_mx1.h"
+
 template <int TAPS, int EPI>
 static void launch_mx_epi(const ConvGemmParams& p, hipStream_t s) {
     const int grid = (p.M / PH_BM) * (p.N / 128);
@@ -348,6 +350,7 @@ static void launch_mx_epi(const ConvGemmParams& p, hipStream_t s) {
 // epilogue variant of a DT_MX launch, or -1: fp32 output with the split-precision path's operand sets, each with or without the plane
 // set of the result (EPI_MXP); planes-only for conv1 of a ResBlock pair (its fp32 value has no other reader)
 static int mx_epi_variant(const ConvGemmParams& p) {
+    if (p.taps == 1) return mx1_epi_variant(p);
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
     const bool odd_slope = p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f);
     const bool mxp = p.mxo_h != nullptr;
@@ -398,12 +401,14 @@ static hipError_t mx_set_attributes() {
     r = mx_attr_taps<3>(); if (r != hipSuccess) e = r;
     r = mx_attr_taps<7>(); if (r != hipSuccess) e = r;
     r = mx_attr_taps<11>(); if (r != hipSuccess) e = r;
+    r = mx1_set_attributes(); if (r != hipSuccess) e = r;
     return e;
 }
 
 // Which calls take the MX kernel is a function of the layer's shape only (never of M): an utterance gets the same arithmetic alone
 // and inside a batch.  Everything else of a DT_MX call runs as the split-precision (three fp16 MFMAs) kernel.
 static bool mx_shape_ok(const ConvGemmParams& p) {
+    if (p.taps == 1) return mx1_shape_ok(p);          // nn.Linear: the one-tap pipeline (ev_gemm_mx1.h)
     return p.W_mx && p.N % 128 == 0 && p.K % 128 == 0 && (p.taps == 3 || p.taps == 7 || p.taps == 11) && p.M % PH_BM == 0 &&
            p.lda == p.K && (p.taps - 1) * p.dil <= MAX_SPAN;
 }
@@ -438,6 +443,7 @@ static void launch_mx(const ConvGemmParams& p_in, hipStream_t s) {
         p.A = H; p.lda = p.K; p.pro_lrelu = 0;
         p.mx_x4[0] = x4h; p.mx_x4[1] = x4l; p.mx_xs[0] = sh; p.mx_xs[1] = sl; p.mx_xs_stride = s_stride;
     }
+    if (p.taps == 1) { launch_mx1_kernel(p, s); return; }
     const int e = mx_epi_variant(p);
     switch (p.taps) {
         case 3: launch_mx_taps<3>(p, e, s); break;

@@ -149,6 +149,13 @@ class _Blob:
             from .mxfp4 import pack_weight_planes
             self.raw(name, pack_weight_planes(w))
 
+    def mx1(self, name: str, w: np.ndarray):
+        """fp4 planes of an nn.Linear weight [N][1][K] (N, K multiples of 128) for the one-tap MX GEMM (gemm_mx1_kernel): the same plane layout."""
+        N, taps, K = w.shape
+        if N % 128 == 0 and K % 128 == 0 and taps == 1:
+            from .mxfp4 import pack_weight_planes
+            self.raw(name, pack_weight_planes(w))
+
     def mx_pair(self, name: str, w: np.ndarray):
         """fp4 planes of a C = 32 ResBlock conv for the fused MX pair kernel (mxfp4.pack_pair_weight_planes)."""
         N, taps, K = w.shape
@@ -224,6 +231,8 @@ def pack_state_dict(sd: Dict[str, object], shapes=None, pe_len: int = 4096) -> T
                 b.lo(f"{short}.{i}.ffn1.w32l", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))
                 b.mx(f"{short}.{i}.ffn1.wmx", _conv_to_gemm(f32(f"{p}.feed_forward.w_1.weight")))       # "mx" decoder: conv-FFN on the MX kernel
                 b.mx(f"{short}.{i}.ffn2.wmx", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
+                b.mx1(f"{short}.{i}.qkv.wmx", np.concatenate(wq, 0)[:, None, :])                           # ... and the QKV / output projections on the one-tap MX GEMM
+                b.mx1(f"{short}.{i}.out.wmx", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])
                 b.lo(f"{short}.{i}.ffn2.w32l", _conv_to_gemm(f32(f"{p}.feed_forward.w_2.weight")))
             b.add(f"{short}.{i}.qkv.b", np.concatenate(bq, 0), DT_F32)
             b.both(f"{short}.{i}.out.w", f32(f"{p}.self_attn.linear_out.weight")[:, None, :])

@@ -699,6 +699,54 @@ def test_mx_conv_gemm_fp32_input(lib, Cc, N, k, dil, M):
     assert _rel(emu, exact) > 1e-6          # (the test would be vacuous if the emulation were exact)
 
 
+@pytest.mark.parametrize("K,N,M,res", [(384, 1152, 256 * 5, False), (384, 384, 256 * 3, True), (128, 128, 256 * 2, False), (1536, 384, 256 * 2, True)])
+def test_mx_one_tap_gemm(lib, K, N, M, res):
+    """gemm_mx1_kernel (ev_gemm_mx1.h): nn.Linear in the MX arithmetic (the mel decoder's QKV / output projections): fp32 activation ->
+    mx_planes_kernel -> one fp16 MFMA + two block-scaled fp4 MFMAs per product, one column block per pipeline step.  fp64 references: the same
+    arithmetic with the host quantiser (tight) and the exact product (the MX error level); invalid row groups incl. a whole all-gap tile; the residual
+    variant runs in place like the engine's."""
+    torch.manual_seed(K + N + M)
+    x = torch.randn(M, K, device="cuda") * torch.exp(0.5 * torch.randn(M, 1, device="cuda"))
+    w = torch.randn(N, K, 1, device="cuda") / math.sqrt(K)
+    bias = torch.randn(N, device="cuda")
+    wts = _mx_weights(w)
+    valid = torch.ones(M // 64, dtype=torch.uint8, device="cuda")
+    valid[1] = 0
+    valid[4:8] = 0                          # rows 256 .. 511: one whole tile
+    vrow = valid.bool().repeat_interleave(64).cpu()
+    r0 = torch.randn(M, N, device="cuda")
+    out = r0.clone() if res else torch.full((M, N), 7.0, device="cuda")
+    nb = lib.ev_op_mx_scratch_bytes(M, K)
+    scratch = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    d = _mx_desc(lib, wts, M, N, K, 1, 1, bias)
+    d.center = 0
+    d.A, d.lda = x.data_ptr(), K
+    d.row_valid, d.valid_shift = valid.data_ptr(), 6
+    d.mx_scratch, d.mx_scratch_size = scratch.data_ptr(), nb
+    d.out32 = out.data_ptr()
+    if res:
+        d.res, d.res_dtype, d.ldres = out.data_ptr(), 1, N
+    _launch(lib, d)
+    ah, qah, qal, _ = _mx_act_parts(x.cpu())
+    emu = _conv64(ah, wts["wh"], 1, 1) + _conv64(qah, wts["qwl"], 1, 1) + _conv64(qal, wts["qwh"], 1, 1) + bias.double().cpu()
+    exact = _conv64(x.double().cpu(), wts["w"], 1, 1) + bias.double().cpu()
+    if res:
+        emu, exact = emu + r0.double().cpu(), exact + r0.double().cpu()
+    emu[~vrow] = 0
+    exact[~vrow] = 0
+    got = out.cpu().double()
+    assert float(out[~vrow.cuda()].abs().max()) == 0.0
+    assert _rel(got, emu) < 2e-6, (K, N, _rel(got, emu))
+    assert _rel(got, exact) < 1.5e-4, (K, N, _rel(got, exact))
+    assert _rel(emu, exact) > 1e-6
+    out2 = r0.clone() if res else torch.full((M, N), 7.0, device="cuda")          # run to run
+    d.out32 = out2.data_ptr()
+    if res:
+        d.res = out2.data_ptr()
+    _launch(lib, d)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("Cc,N,k,dil,tiles_m", [(128, 128, 3, 5, 1100), (256, 256, 7, 1, 600), (128, 128, 11, 3, 530)])
 def test_mx_conv_gemm_long_tile_list_with_all_gap_tiles(lib, Cc, N, k, dil, tiles_m):
     """conv_gemm_mx_kernel on more tiles than the chip holds at once (several residency rounds), with invalid row groups -- incl. whole all-gap

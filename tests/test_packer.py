@@ -146,7 +146,18 @@ def test_mx_weight_planes(packed):
     mx = sorted(k for k in t if k.endswith(".wmx"))
     pmx = sorted(k for k in t if k.endswith(".wpmx"))
     assert [k for k in mx if k.startswith("voc.up")] == ["voc.up0.wmx", "voc.up1.wmx", "voc.up2.wmx"]
-    assert sorted(k for k in mx if k.startswith("dec.")) == sorted("dec.%d.ffn%d.wmx" % (i, j) for i in range(4) for j in (1, 2))
+    # decoder: the conv-FFN (3 taps: conv_gemm_mx_kernel) and, since round 4, the QKV / output projections (1 tap: gemm_mx1_kernel)
+    assert sorted(k for k in mx if k.startswith("dec.")) == sorted(["dec.%d.ffn%d.wmx" % (i, j) for i in range(4) for j in (1, 2)] +
+                                                                   ["dec.%d.%s.wmx" % (i, n) for i in range(4) for n in ("qkv", "out")])
+    assert not [k for k in mx if k.startswith("enc.")]              # the token-rate encoder stays fp32-class (bit-exact durations)
+    wq = t["dec.0.qkv.w16"].astype(np.float32) + t["dec.0.qkv.w32l"].astype(np.float32) / 2048.0
+    assert wq.shape == (1152, 1, 384)
+    blob = t["dec.0.qkv.wmx"].view(np.uint8)
+    want = mxfp4.pack_weight_planes(wq)
+    assert blob.size in (want.size, want.size + 1)
+    ql, qh = mxfp4.weight_planes_dequant(blob[:want.size], 1152, 1, 384)
+    w16q = t["dec.0.qkv.w16"].astype(np.float32)
+    assert np.linalg.norm(qh - w16q) / np.linalg.norm(w16q) < 0.2 and np.linalg.norm(ql - (wq - w16q)) / np.linalg.norm(wq - w16q) < 0.25
     assert len([k for k in mx if ".rb" in k]) == 2 * 3 * 3 * 2 and all(int(k.split(".")[1][2:]) < 6 for k in mx if ".rb" in k)
     cmx = sorted(k for k in t if k.endswith(".wcmx"))            # C = 64: stage 2 + the last up-conv
     assert len(cmx) == 3 * 3 * 2 + 1 and "voc.up3.wcmx" in cmx and all(6 <= int(k.split(".")[1][2:]) < 9 for k in cmx if ".rb" in k)
