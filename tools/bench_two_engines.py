@@ -23,13 +23,16 @@ from emotivoice_amd.sharding import broadcast_blob  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--precision", default="mx")
+    ap.add_argument("--split", action="store_true", help="ONE batch of 32 as two half-batches of 16 on two handles (intra-step pipelining) against one handle with 32")
     a = ap.parse_args()
-    args = types.SimpleNamespace(mode="am_vocoder", batch=32, sub_batches=1, phonemes=256)
+    args = types.SimpleNamespace(mode="am_vocoder", batch=16 if a.split else 32, sub_batches=1, phonemes=256)
+    args32 = types.SimpleNamespace(mode="am_vocoder", batch=32, sub_batches=1, phonemes=256)
     blob = broadcast_blob(0, 1, 0, None, dur_mode="bench")
     dev = torch.device("cuda", 0)
     engs, works = [], []
     for i in range(2):
-        e = EVEngine(device_id=0, precision="fast")
+        e = EVEngine(device_id=0, precision=a.precision)
         e.load_blob_device(blob.data_ptr(), blob.numel(), keepalive=blob)
         engs.append(e)
         works.append(bench.Workload(args, e, i, dev, torch, _ffi))
@@ -44,8 +47,16 @@ def main():
     for w in works:
         run(w, 2, [])
     torch.cuda.synchronize()
-    for label, pairs in (("one handle, 2n batches", [(works[0], 2 * a.steps)]), ("two handles, n batches each", [(works[0], a.steps), (works[1], a.steps)]),
-                         ("one handle, 2n batches", [(works[0], 2 * a.steps)]), ("two handles, n batches each", [(works[0], a.steps), (works[1], a.steps)])):
+    cases = (("one handle, 2n batches", [(works[0], 2 * a.steps)]), ("two handles, n batches each", [(works[0], a.steps), (works[1], a.steps)]),
+             ("one handle, 2n batches", [(works[0], 2 * a.steps)]), ("two handles, n batches each", [(works[0], a.steps), (works[1], a.steps)]))
+    if a.split:
+        e32 = EVEngine(device_id=0, precision=a.precision)
+        e32.load_blob_device(blob.data_ptr(), blob.numel(), keepalive=blob)
+        w32 = bench.Workload(args32, e32, 0, dev, torch, _ffi)
+        run(w32, 2, [])
+        cases = (("one handle, n batches of 32", [(w32, a.steps)]), ("two handles, n half-batches of 16 each", [(works[0], a.steps), (works[1], a.steps)]),
+                 ("one handle, n batches of 32", [(w32, a.steps)]), ("two handles, n half-batches of 16 each", [(works[0], a.steps), (works[1], a.steps)]))
+    for label, pairs in cases:
         outs = []
         ths = [threading.Thread(target=run, args=(w, n, outs)) for w, n in pairs]
         torch.cuda.synchronize()
