@@ -336,30 +336,54 @@ __device__ __forceinline__ long mx_scale_offset(const ConvGemmParams& p, long li
     const unsigned c = p.mxo_logC ? ((unsigned)lin & ((1u << p.mxo_logC) - 1u)) : (unsigned)co;
     return (long)(c >> 7) * p.mxo_qs_stride + row * 4 + ((c >> 5) & 3);
 }
-// (so = mx_scale_offset of the element: the caller advances it by 4 bytes per plane-set row instead of recomputing it -- ~12 VALU per call)
-__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long lin, long so, int lane) {
+// A wave-uniform pointer pinned to an SGPR pair, opaque to the optimiser (an empty asm with an "s" constraint; readfirstlane folds away when the value
+// already is scalar, and LLVM then re-associates `uniform + zext(lane offset)` into one 64-bit VALU add per access instead of the `saddr + voffset`
+// addressing form).  The value must be wave-uniform.
+template <typename T>
+__device__ __forceinline__ T* uptr(T* q) {
+    unsigned long long b = reinterpret_cast<unsigned long long>(q);
+    asm("" : "+s"(b));
+    typedef __attribute__((address_space(1))) T* gptr;        // (an integer -> pointer cast alone gives a generic pointer: flat_load / flat_store)
+    return (T*)(gptr)b;
+}
+// ... and the lane part re-issued where it is used: hoisted out of the unrolled row loop, its zero-extension lives in another basic block, instruction
+// selection no longer sees `sgpr + zext(vgpr32)` and falls back to a 64-bit VALU add per access (no instruction is emitted for this)
+__device__ __forceinline__ unsigned vlane(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+// (so = mx_scale_offset of the element: the caller advances it by 4 bytes per plane-set row instead of recomputing it -- ~12 VALU per call.
+//  Addresses are split into a wave-uniform 64-bit part (ulin / uso: SALU arithmetic, an SGPR base) and a 32-bit lane part (llin / lso, fixed per
+//  lane for the whole epilogue): the stores take the `saddr + voffset` form and cost no 64-bit VALU adds per row)
+__device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long ulin, unsigned llin_, long uso, unsigned lso_, int lane) {
     uint4 ho;
     unsigned ch, cl, bh, bl;
     mx_quant8(a, ho, ch, cl, bh, bl);
+    const unsigned lh = vlane(llin_ * 2u), lq = vlane(llin_ >> 1), lso = vlane(lso_);      // (the products are loop-invariant: hoisted, re-issued as moves)
+    char* const ph = uptr(reinterpret_cast<char*>(p.mxo_h) + ulin * 2);
+    char* const pq0 = uptr(reinterpret_cast<char*>(p.mxo_q4[0]) + (ulin >> 1));
+    char* const pq1 = uptr(reinterpret_cast<char*>(p.mxo_q4[1]) + (ulin >> 1));
 #ifdef EV_MX_ABL            // tuning build (tools/bench_mxgemm.py): reserved0 bit 6 = no plane stores at all, bit 7 = fp16 hi plane only, bit 8 = no scale bytes
     const int abl = p.reserved0 >> 4;
-    if (abl & 4) { if (p.M < 0) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = uint4{ho.x ^ ch, ho.y ^ cl, ho.z ^ bh, ho.w ^ bl}; return; }
-    if (abl & 8) { if (p.M < 0) ho.x ^= ch ^ cl ^ bh ^ bl; *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho; return; }
+    if (abl & 4) { if (p.M < 0) *reinterpret_cast<uint4*>(ph + lh) = uint4{ho.x ^ ch, ho.y ^ cl, ho.z ^ bh, ho.w ^ bl}; return; }
+    if (abl & 8) { if (p.M < 0) ho.x ^= ch ^ cl ^ bh ^ bl; *reinterpret_cast<uint4*>(ph + lh) = ho; return; }
     if (abl & 16) {
         if (p.M < 0) ho.x ^= bh ^ bl;
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho;
-        *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
-        *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;
+        *reinterpret_cast<uint4*>(ph + lh) = ho;
+        *reinterpret_cast<unsigned*>(pq0 + lq) = ch;
+        *reinterpret_cast<unsigned*>(pq1 + lq) = cl;
         return;
     }
 #endif
-    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.mxo_h) + lin * 2) = ho;
-    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (lin >> 1)) = ch;
-    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (lin >> 1)) = cl;
+    *reinterpret_cast<uint4*>(ph + lh) = ho;
+    *reinterpret_cast<unsigned*>(pq0 + lq) = ch;
+    *reinterpret_cast<unsigned*>(pq1 + lq) = cl;
     if ((lane & 3) == 0) {
-        reinterpret_cast<uint8_t*>(p.mxo_qs[0])[so] = (uint8_t)bh;
-        reinterpret_cast<uint8_t*>(p.mxo_qs[1])[so] = (uint8_t)bl;
+        uptr(reinterpret_cast<uint8_t*>(p.mxo_qs[0]) + uso)[lso] = (uint8_t)bh;
+        uptr(reinterpret_cast<uint8_t*>(p.mxo_qs[1]) + uso)[lso] = (uint8_t)bl;
     }
+}
+// wave-uniform copy of a 64-bit value (lane 0's)
+__device__ __forceinline__ long uniform64(long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
 }
 __device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
@@ -373,6 +397,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     const int rr = lane / LPR, g = lane % LPR;
     const int co = co0 + g * 8;
     const int trow = t0 + rr;                                  // row of (pass 0, it 0); + pass * 32 + it * RPI
+    // Every tensor address below = wave-uniform 64-bit part (rows t0u + pass * 32 + it * RPI, channel co0u: SALU, an SGPR base) + a 32-bit lane
+    // part (row rr, channel g * 8) that is fixed for the whole epilogue: global_load / global_store `saddr + voffset`, no 64-bit VALU adds per row.
+    const int t0u = __builtin_amdgcn_readfirstlane(t0), co0u = __builtin_amdgcn_readfirstlane(co0);
+    const unsigned l_o0 = (unsigned)(rr * p.ldo + g * 8), l_res0 = (unsigned)(rr * p.ldres + g * 8), l_acc0 = (unsigned)(rr * p.ldacc + g * 8),
+                   l_add0 = (unsigned)(rr * p.ldadd + g * 8);                      // in elements; the byte offsets below are what the accesses use
+    const unsigned b_o32 = l_o0 * 4u, b_o16 = l_o0 * 2u, b_res16 = l_res0 * 2u, b_res32 = l_res0 * 4u, b_resq = l_res0 >> 1, b_acc = l_acc0 * 4u, b_add = l_add0 * 2u;
 
     // one byte load per 32-row pass (lane l <-> row l & 31), turned into a wave-uniform bit mask by a ballot: no VGPRs held
     const uint8_t* vptr = p.row_valid ? p.row_valid : g_row_always_valid;
@@ -384,34 +414,39 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     float4 r32[2][IT][2], a32[2][IT][2];
     uint4 rph[2][IT];                       // EPI_RESPL: 8 fp16 hi parts, 8 fp4 remainder codes, the block's scale byte
     unsigned rpc[2][IT], rps[2][IT];
-    long rp_soff = 0;
-    if constexpr (EPI & EPI_RESPL) rp_soff = (long)(co >> 7) * p.res_xs_stride + ((co >> 5) & 3);
+    long rp_su = 0;                         // scale byte of (row, co): [co >> 7][row][(co >> 5) & 3]; lane 0 has the lowest address of the wave
+    unsigned rp_sl0 = 0;
+    if constexpr (EPI & EPI_RESPL) {
+        const long so = (long)(co >> 7) * p.res_xs_stride + ((co >> 5) & 3) + (long)rr * 4;
+        rp_su = uniform64(so) + (long)t0u * 4;
+        rp_sl0 = (unsigned)(so - uniform64(so));
+    }
     constexpr bool LEAN = (EPI & EPI_LEAN) != 0;
 #define EV_EPI_SET(PASS) (LEAN ? 0 : ((PASS) & 1))
 #define EV_EPI_PREFETCH(PASS)                                                                                              \
     _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                                                    \
-        const long t_ = trow + (PASS) * 32 + it * RPI;                                                                     \
+        const long tu_ = t0u + (PASS) * 32 + it * RPI;                                                                     \
         if constexpr (EPI & EPI_RES16)                                                                                     \
-            r16[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.res) + t_ * p.ldres + co); \
+            r16[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.res) + (tu_ * p.ldres + co0u) * 2) + vlane(b_res16)); \
         if constexpr (EPI & EPI_RES32) {                                                                                   \
-            const float* rp_ = reinterpret_cast<const float*>(p.res) + t_ * p.ldres + co;                                  \
+            const char* rp_ = uptr(reinterpret_cast<const char*>(p.res) + (tu_ * p.ldres + co0u) * 4) + vlane(b_res32);    \
             r32[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const float4*>(rp_);                                          \
-            r32[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const float4*>(rp_ + 4);                                      \
+            r32[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const float4*>(rp_ + 16);                                     \
         }                                                                                                                  \
         if constexpr (EPI & EPI_RESPL) {                                                                                   \
-            const long lin_ = t_ * p.ldres + co;                                                                           \
-            rph[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.res) + lin_ * 2);  \
-            rpc[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p.res_x4) + (lin_ >> 1)); \
-            rps[EV_EPI_SET(PASS)][it] = reinterpret_cast<const uint8_t*>(p.res_xs)[rp_soff + t_ * 4];                      \
+            const long ulin_ = tu_ * p.ldres + co0u;                                                                       \
+            rph[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.res) + ulin_ * 2) + vlane(b_res16));  \
+            rpc[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const unsigned*>(uptr(reinterpret_cast<const char*>(p.res_x4) + (ulin_ >> 1)) + vlane(b_resq)); \
+            rps[EV_EPI_SET(PASS)][it] = uptr(reinterpret_cast<const uint8_t*>(p.res_xs) + (rp_su + ((PASS) * 32 + it * RPI) * 4))[vlane(rp_sl0)]; \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ACC32) {                                                                                   \
-            const float* ap_ = p.acc32 + t_ * p.ldacc + co;                                                                \
+            const char* ap_ = uptr(reinterpret_cast<const char*>(p.acc32) + (tu_ * p.ldacc + co0u) * 4) + vlane(b_acc);    \
             a32[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const float4*>(ap_);                                          \
-            a32[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const float4*>(ap_ + 4);                                      \
+            a32[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const float4*>(ap_ + 16);                                     \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ADD16) {                                                                                   \
-            a16[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_a) + t_ * p.ldadd + co); \
-            a16[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.add16_b) + t_ * p.ldadd + co); \
+            a16[EV_EPI_SET(PASS)][it][0] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.add16_a) + (tu_ * p.ldadd + co0u) * 2) + vlane(b_add)); \
+            a16[EV_EPI_SET(PASS)][it][1] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.add16_b) + (tu_ * p.ldadd + co0u) * 2) + vlane(b_add)); \
         }                                                                                                                  \
     }
     if constexpr (!LEAN) { EV_EPI_PREFETCH(0) }
@@ -437,20 +472,28 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     const f32x2 post_slope2 = f32x2{p.post_slope, p.post_slope};
     const f32x2 mxo_slope2 = f32x2{p.mxo_slope, p.mxo_slope};
     const f32x2 res_inv2 = f32x2{p.res_inv_slope, p.res_inv_slope};
-    const bool mxo_act = p.mxo_slope != 1.0f, scaled = p.out_scale != 1.0f;          // (x * 1 is exact: skipping it changes no bit)
+    // (x * 1 is exact: skipping it changes no bit.  Compared as bit patterns: a float compare of two kernel arguments is a VALU compare whose lane mask the
+    // unrolled loop below keeps re-deriving through a VGPR; the integer compare is one s_cmp)
+    const bool mxo_act = __float_as_uint(p.mxo_slope) != 0x3f800000u, scaled = __float_as_uint(p.out_scale) != 0x3f800000u;
     __half* const o16 = reinterpret_cast<__half*>(p.out16);
     float* const o32a = p.out32_before_post ? p.out32 : nullptr;
     float* const o32b = p.out32_before_post ? nullptr : p.out32;
-    const long rowoff = (long)trow * p.ldo + co;
+    const long rowoff_u = (long)t0u * p.ldo + co0u;             // uniform part of the output offsets; the lane part is l_o
     unsigned lrbit[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) lrbit[it] = 1u << (it * RPI + rr);
     // plane-set output: the lane's scale byte moves by a fixed distance per output row (ldo == N is a multiple of the plane set's C, so a
     // step of one [M][N] row is N / C whole plane-set rows and the channel block stays the lane's own)
-    long mx_so0 = 0;
+    long mx_su = 0;
+    unsigned mx_sl = 0;
     int mx_sstep = 0;
     if constexpr (EPI & EPI_MXP) {
-        mx_so0 = mx_scale_offset(p, rowoff, (long)trow, co);
+        // (the lanes of a wave cover 64 channels from a multiple of 64: one 128-channel group of one plane-set row per output row, so lane 0's scale
+        //  byte has the lowest address of the wave whatever the plane geometry)
+        static_assert(TC == 64, "plane-set epilogue: 64-channel wave tiles");
+        const long so = mx_scale_offset(p, rowoff_u + l_o0, (long)trow, co);
+        mx_su = uniform64(so);
+        mx_sl = (unsigned)(so - mx_su);
         mx_sstep = 4 * (p.mxo_logC ? (p.ldo >> p.mxo_logC) : 1);
     }
     EV_STAMP()
@@ -481,7 +524,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32);
                 lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32 + 16);
             }
-            const long off = rowoff + (long)(pass * 32 + it * RPI) * p.ldo;
+            const long off_u = rowoff_u + (long)(pass * 32 + it * RPI) * p.ldo;
             const f32x4 v0 = lv[it][0], v1 = lv[it][1];
             f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
 #pragma unroll
@@ -524,7 +567,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                     v[j] += f32x2{min_raw(a[j][0], t[0]), min_raw(a[j][1], t[1])};
                 }
             }
-            if (scaled) {
+            if (scaled) {                 // (a real branch: as a select it is 12 VALU per 8 outputs in every launch that does not scale, and the two
+                                          // value sets it creates cost another 12 moves at the row-mask join below)
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= out_scale2;
             }
@@ -548,25 +593,25 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             // (an EPI_MXP launch has no run-time outputs either: mx_epi_variant admits plane sets only beside / instead of ONE fp32 output)
             constexpr bool STATIC_OUT = (EPI & (EPI_O16 | EPI_O32 | EPI_MXP)) != 0;
             if (!STATIC_OUT && o32a) {
-                float* op = o32a + off;
+                char* op = uptr(reinterpret_cast<char*>(o32a + off_u)) + vlane(b_o32);
                 *reinterpret_cast<float4*>(op) = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
+                *reinterpret_cast<float4*>(op + 16) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
             }
             if (!(EPI & EPI_MXP) && has_post) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = lrelu2(v[j], post_slope2);
             }
             if ((EPI & EPI_O32) || (!STATIC_OUT && o32b)) {
-                float* op = o32b + off;
+                char* op = uptr(reinterpret_cast<char*>(o32b + off_u)) + vlane(b_o32);
                 *reinterpret_cast<float4*>(op) = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
+                *reinterpret_cast<float4*>(op + 16) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
             }
             if ((EPI & EPI_O16) || (!STATIC_OUT && o16)) {
                 uint4 o;
                 half2v* h = reinterpret_cast<half2v*>(&o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h[j] = __builtin_convertvector(v[j], half2v);
-                *reinterpret_cast<uint4*>(o16 + off) = o;
+                *reinterpret_cast<uint4*>(uptr(reinterpret_cast<char*>(o16 + off_u)) + vlane(b_o16)) = o;
             }
             if constexpr (EPI & EPI_MXP) {            // the consumer's leaky-relu, then its operand planes (ldo == N: `off` is the linear offset)
                 f32x2 am[4];
@@ -576,7 +621,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
                     for (int j = 0; j < 4; ++j) am[j] = lrelu2(v[j], mxo_slope2);
                 }
-                mx_emit_planes(p, am, off, mx_so0 + (long)((pass * 32 + it * RPI) * mx_sstep), lane);
+                mx_emit_planes(p, am, off_u, l_o0, mx_su + (long)((pass * 32 + it * RPI) * mx_sstep), mx_sl, lane);
             }
             EV_STAMP()
         }
