@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVHIP_LIB", os.path.join(_HERE, "csrc", "libevhip.so"))
-EV_ABI_VERSION = 2
+EV_ABI_VERSION = 3
 EV_PREC_F16, EV_PREC_F32, EV_PREC_X3, EV_PREC_MX = 0, 1, 2, 3
 EV_FLAG_DEVICE_INPUTS, EV_FLAG_NO_VOCODER, EV_FLAG_WANT_INT16, EV_FLAG_FORCED_DURATIONS = 1, 2, 4, 8
 
@@ -27,7 +27,7 @@ class ev_config(C.Structure):
         ("sample_rate", C.c_int32), ("decoder_precision", C.c_int32), ("keep_stages", C.c_int32),
         ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("vocoder_streams", C.c_int32),
         ("vocoder_precision", C.c_int32), ("mx_residual", C.c_int32), ("decoder_attention", C.c_int32),
-        ("fused_pairs", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("fused_pairs", C.c_int32), ("mx_mrf", C.c_int32), ("decoder_ln_planes", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -72,6 +72,7 @@ class ev_conv_gemm_desc(C.Structure):
         ("mxo_h", C.c_void_p), ("mxo_q4", C.c_void_p * 2), ("mxo_qs", C.c_void_p * 2), ("mxo_qs_stride", C.c_uint),
         ("mxo_logC", C.c_int), ("mxo_slope", C.c_float), ("reserved3", C.c_int),
         ("res_x4", C.c_void_p), ("res_xs", C.c_void_p), ("res_xs_stride", C.c_uint), ("res_inv_slope", C.c_float),
+        ("acc_h", C.c_void_p), ("acc_x4", C.c_void_p), ("acc_xs", C.c_void_p), ("acc_xs_stride", C.c_uint), ("mxo_partial", C.c_int),
     ]
 
 
@@ -113,6 +114,7 @@ SIGNATURES = {
     "ev_op_resblock_pair_c32_mx": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_resblock_pair_c64_mx": (C.c_int, [C.POINTER(ev_res_pair_desc), _P]),
     "ev_op_layernorm": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_float, _P, _P]),
+    "ev_op_layernorm_planes": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, C.c_uint, _P]),
     "ev_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
 }
 

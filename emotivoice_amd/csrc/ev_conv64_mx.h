@@ -722,7 +722,7 @@ static bool conv64_mx_eligible(const ConvGemmParams& p) {
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
     return p.W_mx && p.N == 64 && p.K == 64 && p.lda == 64 && (p.taps == 3 || p.taps == 7 || p.taps == 11) && p.M % 256 == 0 && (p.taps - 1) * p.dil <= MAX_SPAN &&
            p.center * 2 == p.taps - 1 && p.mx_x4[0] && p.mx_x4[1] && p.mx_xs[0] && p.mx_xs[1] && !p.pro_lrelu && (p.out32 || p.mxo_h) && !p.out16 && !p.seq_bias &&
-           !p.add16_a && !p.post_lrelu && !p.out32_before_post && !rare_act && (!p.out32 || p.ldo == 64) &&
+           !p.add16_a && !p.post_lrelu && !p.out32_before_post && !rare_act && (!p.out32 || p.ldo == 64) && !p.acc_h && !p.mxo_partial &&
            (!p.mxo_h || (p.mxo_logC == 6 && p.mxo_q4[0] && p.mxo_q4[1] && p.mxo_qs[0] && p.mxo_qs[1] && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f)) &&
            (!p.res || p.res_dtype == DT_F32 || (p.res_dtype == DT_MX && p.res_x4 && p.res_xs && p.ldres == 64 && p.res_inv_slope >= 1.0f)) &&
            (!p.acc32 || p.res) && (!p.res || p.act == ACT_NONE) && (p.res || p.out_scale == 1.0f) &&        // (out_scale lives in the residual branch)

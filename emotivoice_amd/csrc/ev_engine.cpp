@@ -397,11 +397,6 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         WPTR(wout, char, lp + ".out." + wsuf); WPTR(bout, float, lp + ".out.b");
         WPTR(wf1, char, lp + ".ffn1." + wsuf); WPTR(bf1, float, lp + ".ffn1.b");
         WPTR(wf2, char, lp + ".ffn2." + wsuf); WPTR(bf2, float, lp + ".ffn2.b");
-        LayerNormParams ln{};
-        ln.x = (const float*)x.p; ln.ldx = C; ln.rows = rc.R; ln.C = C; ln.gamma = g1; ln.beta = b1; ln.eps = 1e-12f;
-        ln.row_valid = rc.valid; ln.ldo = C;
-        if (prec == DT_F16) ln.out16 = hbuf.p; else ln.out32 = (float*)hbuf.p;
-        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
         ConvGemmParams p = gemm_defaults();
         p.dtype = prec; p.A = hbuf.p; p.lda = C; p.W = wqkv; p.bias = bqkv; p.M = rc.R; p.N = 3 * C; p.K = C;
         p.row_valid = rc.valid; p.ldo = 3 * C;
@@ -409,7 +404,25 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         if (prec == DT_F16) p.out16 = qkv.p; else p.out32 = (float*)qkv.p;
         // EV_PREC_MX decoder: the QKV / output projections on the one-tap MX GEMM (ev_gemm_mx1.h); their fp32 inputs become plane sets in the scratch
         const bool lin_mx = dmx && p.dtype == DT_F32S && h->wt.count(lp + ".qkv.wmx") && h->wt.count(lp + ".out.wmx");
+        // ... and the two LayerNorms write the plane sets their consumers (QKV, the conv-FFN's first conv) read straight into that scratch: no fp32 copy of
+        // LN(x) and no mx_planes_kernel pass over it (ev_config.decoder_ln_planes = 1 restores the two passes; the planes are the same bits either way)
+        const bool ln_pl = dmx && h->cfg.decoder_ln_planes == 0 && C <= 512 && dmx->scratch_bytes >= mx_scratch_bytes(rc.R, C);
+        const MxScratchPlanes lnp = ln_pl ? mx_scratch_planes(dmx->scratch, rc.R, C) : MxScratchPlanes{};
+        auto ln_to_planes = [&](LayerNormParams& l) {
+            l.out32 = nullptr; l.out16 = nullptr;
+            l.mxo_h = lnp.h; l.mxo_q4[0] = lnp.q4[0]; l.mxo_q4[1] = lnp.q4[1]; l.mxo_qs[0] = lnp.qs[0]; l.mxo_qs[1] = lnp.qs[1]; l.mxo_qs_stride = lnp.qs_stride;
+        };
+        auto planes_in = [&](ConvGemmParams& q) {
+            q.A = lnp.h; q.lda = C; q.mx_x4[0] = lnp.q4[0]; q.mx_x4[1] = lnp.q4[1]; q.mx_xs[0] = lnp.qs[0]; q.mx_xs[1] = lnp.qs[1]; q.mx_xs_stride = lnp.qs_stride;
+        };
+        LayerNormParams ln{};
+        ln.x = (const float*)x.p; ln.ldx = C; ln.rows = rc.R; ln.C = C; ln.gamma = g1; ln.beta = b1; ln.eps = 1e-12f;
+        ln.row_valid = rc.valid; ln.ldo = C;
+        if (prec == DT_F16) ln.out16 = hbuf.p; else ln.out32 = (float*)hbuf.p;
+        if (lin_mx && ln_pl) ln_to_planes(ln);
+        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
         if (lin_mx) { p.dtype = DT_MX; p.W_mx = h->wt[lp + ".qkv.wmx"].ptr; p.mx_scratch = dmx->scratch; p.mx_scratch_size = dmx->scratch_bytes; }
+        if (lin_mx && ln_pl) planes_in(p);
         if (gemm(h, lin_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         AttnParams ap{};
         // decoder in the strict / mx modes: split-precision attention (three fp16 MFMAs per product); the token-rate encoder keeps exact fp32
@@ -424,19 +437,23 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         if (prec == DT_F32 && tok_weights(h, lp + ".out.w", p)) return -1;
         if (lin_mx) { p.dtype = DT_MX; p.W_mx = h->wt[lp + ".out.wmx"].ptr; p.mx_scratch = dmx->scratch; p.mx_scratch_size = dmx->scratch_bytes; }
         if (gemm(h, lin_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
-        ln.gamma = g2; ln.beta = b2;
-        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
         p = gemm_defaults();
         p.dtype = prec; p.A = hbuf.p; p.lda = C; p.W = wf1; p.bias = bf1; p.M = rc.R; p.N = F; p.K = C; p.taps = kf; p.center = (kf - 1) / 2;
         p.row_valid = rc.valid; p.act = ACT_GELU; p.ldo = F;
         if (prec == DT_F32 && tok_weights(h, lp + ".ffn1.w", p)) return -1;
         // EV_PREC_MX decoder: the conv-FFN (72 % of the stack's FLOPs) on the MX kernel; its hidden activation only exists as conv2's operand planes
         const bool ffn_mx = dmx && p.dtype == DT_F32S && h->wt.count(lp + ".ffn1.wmx") && h->wt.count(lp + ".ffn2.wmx");
+        ln.gamma = g2; ln.beta = b2;
+        if (prec == DT_F16) ln.out16 = hbuf.p; else ln.out32 = (float*)hbuf.p;
+        ln.mxo_h = nullptr;
+        if (ffn_mx && ln_pl) ln_to_planes(ln);
+        { KScope ks(h, "layernorm", 0, rc.n_valid * C * 6.0); launch_layernorm(ln, h->stream); }
         MxView fv{};
         if (ffn_mx) {
             fv = mx_view(dmx->ffn, (size_t)rc.R, F);
             fv.logC = 0;                                          // dense [R][F] geometry (F = 1536 is not a power of two)
             p.dtype = DT_MX; p.W_mx = h->wt[lp + ".ffn1.wmx"].ptr; p.mx_scratch = dmx->scratch; p.mx_scratch_size = dmx->scratch_bytes;
+            if (ln_pl) planes_in(p);
             mx_out(p, fv, 1.0f);
         } else if (prec == DT_F16) p.out16 = ffn.p; else p.out32 = (float*)ffn.p;
         if (gemm(h, ffn_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
@@ -499,7 +516,8 @@ struct VocBufs {
     // EV_PREC_MX: plane sets of the up-conv output, conv1's output, the two alternating ResBlock states and the stage output; the
     // planes-kernel scratch of the one fp32 tensor an MX launch reads (conv_pre's output)
     // (pl_t / pl_a / pl_b: one set per ResBlock of a stage when the three run concurrently -- small batches, voc_small_batch -- else only [0])
-    PlaneBuf pl_xu, pl_t[3], pl_a[3], pl_b[3], pl_nxt; char* mx_scratch = nullptr; size_t mx_scratch_bytes = 0;
+    // pl_mrf: the running MRF sum of a stage as a PARTIAL plane set (hi plane, remainder codes, their scales; ev_config.mx_mrf == 0)
+    PlaneBuf pl_xu, pl_t[3], pl_a[3], pl_b[3], pl_nxt, pl_mrf; char* mx_scratch = nullptr; size_t mx_scratch_bytes = 0;
 };
 
 // Small batches (single utterances: the reference's own call pattern): a generator launch is a handful of tiles whose K loops are sequential chains
@@ -587,6 +605,11 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         if (rpl && !keep) p.out32 = nullptr;                   // (kept stages still get the raw up-conv output: the voc_up tap)
         if (gemm(h, p.dtype == DT_MX ? (p.N == 64 && p.K == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx") : gname, p, valid_in, nullptr, 2.0 / 3.0)) return -1;
         const bool next_up_mx = stage_mx && i + 1 < c.n_up && has_mx("voc.up" + std::to_string(i + 1));
+        // MRF sum as partial plane sets (conv_gemm_mx_kernel stages, i.e. >= 128 channels): rb0's last conv writes out_scale * x as fp16 hi plane + fp4 remainder
+        // codes, rb1's adds that to its own and rewrites it in place, rb2's adds it and writes the next up-conv's plane set: 2.53 instead of 4 bytes per element
+        // and transfer (16 -> 10.1 bytes per stage-output element; tools/precision_study_mx.py: 4.17e-4 -> 4.22e-4 on the zero-mean recipe)
+        bool mrf_pl = rpl && !keep && c.mx_mrf == 0 && c.n_rb == 3 && cout % 128 == 0 && next_up_mx && vb.pl_mrf.h;
+        for (int j = 0; mrf_pl && j < c.n_rb; ++j) mrf_pl = c.rb_kernels[j] == 3 || c.rb_kernels[j] == 7 || c.rb_kernels[j] == 11;
         U *= s;
         const int shift = ilog2(U);
         const bool last_stage = (i == c.n_up - 1);
@@ -702,11 +725,15 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     // split-precision mode, use the fp32 running sum.
                     p.out_scale = 1.0f / (float)c.n_rb;
                     const bool mrf16 = (c.n_rb == 3) && !x3;
+                    const MxView mv = mrf_pl ? mx_view(vb.pl_mrf, (size_t)rows_out, cout) : MxView{};
                     if (mrf16) {
                         if (j == 2) { p.add16_a = vb.mrf16a.p; p.add16_b = vb.mrf16b.p; p.ldadd = cout; }
+                    } else if (mrf_pl) {
+                        if (j > 0) { p.acc_h = mv.h; p.acc_x4 = mv.q4[1]; p.acc_xs = mv.qs[1]; p.acc_xs_stride = mv.qs_stride; p.ldacc = cout; }
                     } else if (j > 0) { p.acc32 = (const float*)vb.mrf32.p; p.ldacc = cout; }
                     if (j + 1 < c.n_rb) {
                         if (mrf16) p.out16 = (j == 0) ? vb.mrf16a.p : vb.mrf16b.p;
+                        else if (mrf_pl) { mx_out(p, mv, 1.0f); p.mxo_partial = 1; }
                         else p.out32 = (float*)vb.mrf32.p;
                     } else if (x3) {
                         p.out32 = (float*)vb.nxt[i].p;               // raw MRF mean (= the voc_mrf tap); consumers apply the leaky-relu
@@ -826,7 +853,7 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
             const size_t R = (size_t)Rf * U + 2 * MX_PAD;
             hb = std::max(hb, R * ch * 2); qb = std::max(qb, R * (ch / 2)); sb = std::max(sb, (size_t)std::max(1, ch / 128) * R * 4);
         }
-        std::vector<PlaneBuf*> sets = {&vb.pl_xu, &vb.pl_nxt};
+        std::vector<PlaneBuf*> sets = {&vb.pl_xu, &vb.pl_nxt, &vb.pl_mrf};
         for (int j = 0; j < (per_rb ? 3 : 1); ++j) { sets.push_back(&vb.pl_t[j]); sets.push_back(&vb.pl_a[j]); sets.push_back(&vb.pl_b[j]); }
         for (PlaneBuf* b : sets) {
             if (!hb) break;
@@ -957,8 +984,8 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
         return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
     if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3 && cfg->vocoder_precision != EV_PREC_MX)
         return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16, EV_PREC_X3 or EV_PREC_MX");
-    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs) & ~1)
-        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs must be 0 or 1");
+    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs | cfg->mx_mrf | cfg->decoder_ln_planes) & ~1)
+        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs / mx_mrf / decoder_ln_planes must be 0 or 1");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));
@@ -1605,6 +1632,15 @@ int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const f
     LayerNormParams p{};
     p.x = x; p.ldx = C; p.rows = rows; p.C = C; p.gamma = gamma; p.beta = beta; p.eps = eps; p.row_valid = row_valid; p.out16 = out16;
     p.out32 = out32; p.ldo = C; p.dot_w = dot_w; p.dot_b = dot_b; p.dot_out = dot_out;
+    launch_layernorm(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int ev_op_layernorm_planes(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, const uint8_t* row_valid,
+                           void* h, void* q4h, void* q4l, void* qsh, void* qsl, unsigned qs_stride, void* stream) {
+    if (C > 512 || C % 128 || !h || !q4h || !q4l || !qsh || !qsl) return -2;
+    LayerNormParams p{};
+    p.x = x; p.ldx = C; p.rows = rows; p.C = C; p.gamma = gamma; p.beta = beta; p.eps = eps; p.row_valid = row_valid; p.ldo = C;
+    p.mxo_h = h; p.mxo_q4[0] = q4h; p.mxo_q4[1] = q4l; p.mxo_qs[0] = qsh; p.mxo_qs[1] = qsl; p.mxo_qs_stride = qs_stride;
     launch_layernorm(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "ev_kernels.h"
+#include "ev_mxq.h"
 
 // No implicit FMA contraction in this file.  The engine promises results that do not depend on how an utterance is batched
 // (tests: test_batch_invariance_bit_exact), but which kernel / tile / epilogue variant a GEMM takes DOES depend on the batch's
@@ -285,15 +286,13 @@ extern "C" void ev_trace_flags(int f) { g_trace_flags = f; }
 // MXP: additionally (or, without O32 / O16, only) the MX plane set of lrelu(result, mxo_slope) for a DT_MX consumer (mx_emit_planes).
 // RESPL: the residual comes from a plane set (ConvGemmParams::res_x4 ...): fp16 hi plane + fp4 codes of the remainder + their block scales, 2.5 bytes
 // per element instead of 4, and no fp32 copy of the residual stream has to be written by its producer.
+// ACCPL: the accumulate-in operand is a PARTIAL plane set (ConvGemmParams::acc_h ...: fp16 hi plane + fp4 codes of the remainder + their block scales, no
+// activation) instead of an fp32 tensor; PART (with MXP): the output plane set is such a partial one -- no hi-code plane, no hi scales.  Together they carry the
+// MRF sum of a stage's three ResBlocks at 2.53 instead of 4 bytes per element and transfer (the running sum is re-quantised once per ResBlock).
 enum { EPI_RES16 = 1, EPI_RES32 = 2, EPI_ACC32 = 4, EPI_GENERIC = 8, EPI_RARE_ACT = 16, EPI_O16 = 32, EPI_O32 = 64, EPI_ADD16 = 128, EPI_LEAN = 256,
-       EPI_MXP = 512, EPI_RESPL = 1024 };
+       EPI_MXP = 512, EPI_RESPL = 1024, EPI_ACCPL = 2048, EPI_PART = 4096 };
 
-// ---- MX plane set of an activation (format: ev_gemm_mx.h / emotivoice_amd/mxfp4.py).  E8M0 byte of the block scale 2^(floor(log2 amax) - 2),
-// clamped to [1, 254] (an all-zero block gets 1).
-__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
-    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 2;
-    return (unsigned)min(max(e, 1), 254);
-}
+// ---- MX plane set of an activation (format: ev_gemm_mx.h / emotivoice_amd/mxfp4.py; mx_scale_byte / mx_fp4_code: ev_mxq.h)
 // value of lane ^ 1 / lane ^ 2 (v_mov_b32_dpp quad_perm:[1,0,3,2] / [2,3,0,1])
 __device__ __forceinline__ float quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ float quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
@@ -352,6 +351,7 @@ __device__ __forceinline__ unsigned vlane(unsigned x) { asm volatile("" : "+v"(x
 // (so = mx_scale_offset of the element: the caller advances it by 4 bytes per plane-set row instead of recomputing it -- ~12 VALU per call.
 //  Addresses are split into a wave-uniform 64-bit part (ulin / uso: SALU arithmetic, an SGPR base) and a 32-bit lane part (llin / lso, fixed per
 //  lane for the whole epilogue): the stores take the `saddr + voffset` form and cost no 64-bit VALU adds per row)
+template <bool PART = false>
 __device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f32x2 (&a)[4], long ulin, unsigned llin_, long uso, unsigned lso_, int lane) {
     uint4 ho;
     unsigned ch, cl, bh, bl;
@@ -373,10 +373,10 @@ __device__ __forceinline__ void mx_emit_planes(const ConvGemmParams& p, const f3
     }
 #endif
     *reinterpret_cast<uint4*>(ph + lh) = ho;
-    *reinterpret_cast<unsigned*>(pq0 + lq) = ch;
+    if constexpr (!PART) *reinterpret_cast<unsigned*>(pq0 + lq) = ch;
     *reinterpret_cast<unsigned*>(pq1 + lq) = cl;
     if ((lane & 3) == 0) {
-        uptr(reinterpret_cast<uint8_t*>(p.mxo_qs[0]) + uso)[lso] = (uint8_t)bh;
+        if constexpr (!PART) uptr(reinterpret_cast<uint8_t*>(p.mxo_qs[0]) + uso)[lso] = (uint8_t)bh;
         uptr(reinterpret_cast<uint8_t*>(p.mxo_qs[1]) + uso)[lso] = (uint8_t)bl;
     }
 }
@@ -403,6 +403,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     const unsigned l_o0 = (unsigned)(rr * p.ldo + g * 8), l_res0 = (unsigned)(rr * p.ldres + g * 8), l_acc0 = (unsigned)(rr * p.ldacc + g * 8),
                    l_add0 = (unsigned)(rr * p.ldadd + g * 8);                      // in elements; the byte offsets below are what the accesses use
     const unsigned b_o32 = l_o0 * 4u, b_o16 = l_o0 * 2u, b_res16 = l_res0 * 2u, b_res32 = l_res0 * 4u, b_resq = l_res0 >> 1, b_acc = l_acc0 * 4u, b_add = l_add0 * 2u;
+    const unsigned b_acc16 = l_acc0 * 2u, b_accq = l_acc0 >> 1;
 
     // one byte load per 32-row pass (lane l <-> row l & 31), turned into a wave-uniform bit mask by a ballot: no VGPRs held
     const uint8_t* vptr = p.row_valid ? p.row_valid : g_row_always_valid;
@@ -421,6 +422,15 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
         rp_su = uniform64(so) + (long)t0u * 4;
         rp_sl0 = (unsigned)(so - uniform64(so));
     }
+    uint4 aph[2][IT];                       // EPI_ACCPL: the partial plane set of the accumulate-in operand, as rph / rpc / rps
+    unsigned apc[2][IT], aps[2][IT];
+    long ap_su = 0;
+    unsigned ap_sl0 = 0;
+    if constexpr (EPI & EPI_ACCPL) {
+        const long so = (long)(co >> 7) * p.acc_xs_stride + ((co >> 5) & 3) + (long)rr * 4;
+        ap_su = uniform64(so) + (long)t0u * 4;
+        ap_sl0 = (unsigned)(so - uniform64(so));
+    }
     constexpr bool LEAN = (EPI & EPI_LEAN) != 0;
 #define EV_EPI_SET(PASS) (LEAN ? 0 : ((PASS) & 1))
 #define EV_EPI_PREFETCH(PASS)                                                                                              \
@@ -438,6 +448,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             rph[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.res) + ulin_ * 2) + vlane(b_res16));  \
             rpc[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const unsigned*>(uptr(reinterpret_cast<const char*>(p.res_x4) + (ulin_ >> 1)) + vlane(b_resq)); \
             rps[EV_EPI_SET(PASS)][it] = uptr(reinterpret_cast<const uint8_t*>(p.res_xs) + (rp_su + ((PASS) * 32 + it * RPI) * 4))[vlane(rp_sl0)]; \
+        }                                                                                                                  \
+        if constexpr (EPI & EPI_ACCPL) {                                                                                   \
+            const long ulin_ = tu_ * p.ldacc + co0u;                                                                       \
+            aph[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.acc_h) + ulin_ * 2) + vlane(b_acc16));  \
+            apc[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const unsigned*>(uptr(reinterpret_cast<const char*>(p.acc_x4) + (ulin_ >> 1)) + vlane(b_accq)); \
+            aps[EV_EPI_SET(PASS)][it] = uptr(reinterpret_cast<const uint8_t*>(p.acc_xs) + (ap_su + ((PASS) * 32 + it * RPI) * 4))[vlane(ap_sl0)]; \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ACC32) {                                                                                   \
             const char* ap_ = uptr(reinterpret_cast<const char*>(p.acc32) + (tu_ * p.ldacc + co0u) * 4) + vlane(b_acc);    \
@@ -577,6 +593,15 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
                 const float4 r0 = a32[EV_EPI_SET(pass)][it][0], r1 = a32[EV_EPI_SET(pass)][it][1];
                 v[0] += f32x2{r0.x, r0.y}; v[1] += f32x2{r0.z, r0.w}; v[2] += f32x2{r1.x, r1.y}; v[3] += f32x2{r1.z, r1.w};
             }
+            if constexpr (EPI & EPI_ACCPL) {             // the partial's value is hi + code * 2^(scale - 127), no activation
+                const half2v* h = reinterpret_cast<const half2v*>(&aph[EV_EPI_SET(pass)][it]);
+                const unsigned cw = apc[EV_EPI_SET(pass)][it];
+                const float sc = __uint_as_float(aps[EV_EPI_SET(pass)][it] << 23);
+                v[0] += __builtin_convertvector(h[0], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 0);
+                v[1] += __builtin_convertvector(h[1], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 1);
+                v[2] += __builtin_convertvector(h[2], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 2);
+                v[3] += __builtin_convertvector(h[3], f32x2) + __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(cw, sc, 3);
+            }
             if constexpr (EPI & EPI_ADD16) {
                 const half2v* ha = reinterpret_cast<const half2v*>(&a16[EV_EPI_SET(pass)][it][0]);
                 const half2v* hb = reinterpret_cast<const half2v*>(&a16[EV_EPI_SET(pass)][it][1]);
@@ -621,7 +646,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
                     for (int j = 0; j < 4; ++j) am[j] = lrelu2(v[j], mxo_slope2);
                 }
-                mx_emit_planes(p, am, off_u, l_o0, mx_su + (long)((pass * 32 + it * RPI) * mx_sstep), mx_sl, lane);
+                mx_emit_planes<(EPI & EPI_PART) != 0>(p, am, off_u, l_o0, mx_su + (long)((pass * 32 + it * RPI) * mx_sstep), mx_sl, lane);
             }
             EV_STAMP()
         }

@@ -49,11 +49,6 @@ size_t mx_scratch_bytes(int M, int K) { return mx_layout(M, K).total; }
 
 // ---- fp32 [M][K] -> planes.  One thread = 8 consecutive channels of a row (one 16-byte store of the fp16 plane, one dword of each
 // code plane); the four threads of a 32-channel block agree on the block maxima through two xor-shuffles.
-__device__ __forceinline__ unsigned mx_fp4_code(float y) {          // |y| <= 6 after scaling (larger saturates), round to nearest even
-    const float a = fabsf(y);
-    unsigned c = (a > 0.25f) + (a >= 0.75f) + (a > 1.25f) + (a >= 1.75f) + (a > 2.5f) + (a >= 3.5f) + (a > 5.0f);
-    return c | ((__float_as_uint(y) >> 28) & 8u);
-}
 __global__ __launch_bounds__(256) void mx_planes_kernel(const float* __restrict__ A, int lda, int M, int K, int pro, float slope,
                                                         __half* __restrict__ H, uint8_t* __restrict__ x4h, uint8_t* __restrict__ x4l,
                                                         uint8_t* __restrict__ sh, uint8_t* __restrict__ sl, unsigned s_stride) {
@@ -354,11 +349,21 @@ static int mx_epi_variant(const ConvGemmParams& p) {
     const bool rare_act = p.act != ACT_NONE && p.act != ACT_LRELU;
     const bool odd_slope = p.act == ACT_LRELU && !(p.act_slope >= 0.f && p.act_slope <= 1.f);
     const bool mxp = p.mxo_h != nullptr;
-    if (mxp && !(p.mxo_q4[0] && p.mxo_q4[1] && p.mxo_qs[0] && p.mxo_qs[1] && p.ldo == p.N && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f &&
+    const bool part = p.mxo_partial != 0, accpl = p.acc_h != nullptr;
+    if (mxp && !((part || (p.mxo_q4[0] && p.mxo_qs[0])) && p.mxo_q4[1] && p.mxo_qs[1] && p.ldo == p.N && p.mxo_slope >= 0.f && p.mxo_slope <= 1.f &&
                  (p.mxo_logC == 0 || (p.mxo_logC >= 6 && p.mxo_logC <= 12 && p.N % (1 << p.mxo_logC) == 0)))) return -1;
     if (mxp && rare_act && !p.out32 && !p.res && !p.acc32 && !p.seq_bias && !p.add16_a && !p.out16 && !p.post_lrelu)
         return EPI_RARE_ACT | EPI_MXP;                                       // conv-FFN's first conv: erf-GELU, planes only
     const bool respl = p.res && p.res_dtype == DT_MX;          // residual from a plane set (fp16 hi plane + fp4 remainder codes + scales)
+    if (part || accpl) {
+        // the MRF sum of a stage as partial plane sets: the last conv of a ResBlock adds the running sum (a partial plane set, or nothing for the first
+        // ResBlock) and writes the new one (partial) or -- the last ResBlock -- the next up-conv's full plane set.  Planes only, residual from planes.
+        if (!(respl && mxp && !p.out32 && !p.acc32 && !p.seq_bias && !p.add16_a && !p.out16 && !p.post_lrelu && !odd_slope && !rare_act)) return -1;
+        if (!(p.res_x4 && p.res_xs && p.ldres == p.N && p.res_inv_slope >= 1.0f)) return -1;
+        if (accpl && !(p.acc_x4 && p.acc_xs && p.ldacc == p.N)) return -1;
+        if (part && (p.mxo_slope != 1.0f || !(p.mxo_logC == 0 || (1 << p.mxo_logC) == p.N))) return -1;          // raw values, the launch's own [M][N] geometry
+        return EPI_RESPL | EPI_LEAN | EPI_MXP | (accpl ? EPI_ACCPL : 0) | (part ? EPI_PART : 0);
+    }
     if (p.seq_bias || p.add16_a || p.out16 || p.out32_before_post || p.post_lrelu || odd_slope || rare_act) return (mxp || respl) ? -1 : EPI_GENERIC;
     const bool res32 = p.res && p.res_dtype == DT_F32;
     const int m = mxp ? EPI_MXP : 0;
@@ -378,7 +383,8 @@ static int mx_epi_variant(const ConvGemmParams& p) {
 #define EV_MX_VARIANTS(X) X(EPI_O32) X(EPI_RES32 | EPI_O32 | EPI_LEAN) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_MXP) X(EPI_O32 | EPI_MXP) \
     X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RARE_ACT | EPI_MXP) X(EPI_GENERIC)   \
     X(EPI_RESPL | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_O32 | EPI_LEAN | EPI_MXP)                                    \
-    X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_ACC32 | EPI_LEAN | EPI_MXP)
+    X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_ACC32 | EPI_LEAN | EPI_MXP)           \
+    X(EPI_RESPL | EPI_LEAN | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_LEAN | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_LEAN | EPI_MXP)
 template <int TAPS>
 static void launch_mx_taps(const ConvGemmParams& p, int e, hipStream_t s) {
     switch (e) {
@@ -421,22 +427,31 @@ static bool mx_eligible(const ConvGemmParams& p) {
 // 0 = this DT_MX call can run (as the MX kernel, or -- fp32 input, no plane output -- as the split-precision fallback)
 static bool conv64_mx_eligible(const ConvGemmParams& p);
 int mx_check(const ConvGemmParams& p) {
-    if (p.dtype != DT_MX) return p.mxo_h || mx_planes_in(p) || (p.res && p.res_dtype == DT_MX) ? -1 : 0;       // plane sets exist only between DT_MX launches
+    if (p.dtype != DT_MX) return p.mxo_h || mx_planes_in(p) || (p.res && p.res_dtype == DT_MX) || p.acc_h || p.mxo_partial ? -1 : 0;       // plane sets exist only between DT_MX launches
     if (mx_eligible(p) || conv64_mx_eligible(p)) return 0;
-    return (p.mxo_h || mx_planes_in(p) || !p.W_lo || (p.res && p.res_dtype == DT_MX)) ? -1 : 0;
+    return (p.mxo_h || mx_planes_in(p) || !p.W_lo || (p.res && p.res_dtype == DT_MX) || p.acc_h || p.mxo_partial) ? -1 : 0;
+}
+MxScratchPlanes mx_scratch_planes(void* scratch, int M, int K) {
+    const MxPlaneLayout L = mx_layout(M, K);
+    char* const base = reinterpret_cast<char*>(scratch);
+    const size_t r0 = MX_SLACK;
+    MxScratchPlanes v;
+    v.h = base + L.h + r0 * K * 2;
+    v.q4[0] = base + L.x4h + r0 * (K / 2); v.q4[1] = base + L.x4l + r0 * (K / 2);
+    v.qs[0] = base + L.sh + r0 * 4; v.qs[1] = base + L.sl + r0 * 4;
+    v.qs_stride = (unsigned)(L.rows * 4);
+    return v;
 }
 static void launch_mx(const ConvGemmParams& p_in, hipStream_t s) {
     ConvGemmParams p = p_in;
     if (!mx_planes_in(p)) {
-        const MxPlaneLayout L = mx_layout(p.M, p.K);
-        char* const base = reinterpret_cast<char*>(p.mx_scratch);
-        const size_t r0 = MX_SLACK;
-        __half* H = reinterpret_cast<__half*>(base + L.h + r0 * p.K * 2);
-        uint8_t* x4h = reinterpret_cast<uint8_t*>(base + L.x4h + r0 * (p.K / 2));
-        uint8_t* x4l = reinterpret_cast<uint8_t*>(base + L.x4l + r0 * (p.K / 2));
-        uint8_t* sh = reinterpret_cast<uint8_t*>(base + L.sh + r0 * 4);
-        uint8_t* sl = reinterpret_cast<uint8_t*>(base + L.sl + r0 * 4);
-        const unsigned s_stride = (unsigned)(L.rows * 4);
+        const MxScratchPlanes sp = mx_scratch_planes(p.mx_scratch, p.M, p.K);
+        __half* H = reinterpret_cast<__half*>(sp.h);
+        uint8_t* x4h = reinterpret_cast<uint8_t*>(sp.q4[0]);
+        uint8_t* x4l = reinterpret_cast<uint8_t*>(sp.q4[1]);
+        uint8_t* sh = reinterpret_cast<uint8_t*>(sp.qs[0]);
+        uint8_t* sl = reinterpret_cast<uint8_t*>(sp.qs[1]);
+        const unsigned s_stride = sp.qs_stride;
         const long threads = (long)p.M * (p.K / 8);
         hipLaunchKernelGGL(mx_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(p.A), p.lda, p.M, p.K,
                            p.pro_lrelu, p.pro_slope, H, x4h, x4l, sh, sl, s_stride);

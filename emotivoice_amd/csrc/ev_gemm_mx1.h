@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 4) void gemm_mx1_kernel(const ConvGemmParams p
 
 // epilogue variants of the one-tap kernel: plain fp32 output (QKV), fp32 residual + fp32 output (the attention's output projection, in place)
 static int mx1_epi_variant(const ConvGemmParams& p) {
-    if (p.seq_bias || p.add16_a || p.out16 || p.out32_before_post || p.post_lrelu || p.act != ACT_NONE || p.acc32 || p.mxo_h || !p.out32) return -1;
+    if (p.seq_bias || p.add16_a || p.out16 || p.out32_before_post || p.post_lrelu || p.act != ACT_NONE || p.acc32 || p.acc_h || p.mxo_partial || p.mxo_h || !p.out32) return -1;
     if (!p.res) return EPI_O32;
     return p.res_dtype == DT_F32 ? (EPI_RES32 | EPI_O32 | EPI_LEAN) : -1;
 }

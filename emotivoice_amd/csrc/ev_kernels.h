@@ -66,6 +66,12 @@ struct ConvGemmParams {
     // the epilogue rebuilds x = a' >= 0 ? a' : a' * res_inv_slope, a' = hi + code * scale.  tools/precision_study_mx.py: the generator's waveform error
     // goes from 3.4e-4 to 4.4e-4 on the zero-mean recipe, and a conv2 launch moves 8.7 instead of 14.1 bytes per element.
     const void* res_x4; const void* res_xs; unsigned res_xs_stride; float res_inv_slope;
+    // Accumulate-in from a PARTIAL plane set (conv_gemm_mx_kernel launches with a plane-set residual; excludes acc32): the addend is acc_h (fp16 hi plane,
+    // [M][N], ldacc == N) + acc_x4 (fp4 codes of the remainder, [M][N / 2]) * acc_xs (their E8M0 scales, chunk-major [N / 128][acc_xs_stride / 4 rows][4]) --
+    // a plane set without the hi-code plane and without an activation: 2.53 bytes per element instead of acc32's 4.  mxo_partial != 0: the OUTPUT plane set is
+    // such a partial one (mxo_h, mxo_q4[1], mxo_qs[1]; mxo_q4[0] / mxo_qs[0] unused; mxo_slope must be 1); it may alias the acc_* planes (same rows, same
+    // columns: each element is read before it is rewritten by the same lane).  The MRF running sum of a generator stage travels like this.
+    const void* acc_h; const void* acc_x4; const void* acc_xs; unsigned acc_xs_stride; int mxo_partial;
 };
 // bytes of activation-plane scratch a DT_MX call with an [M][K] input needs
 size_t mx_scratch_bytes(int M, int K);
@@ -113,7 +119,14 @@ struct LayerNormParams {
     const uint8_t* row_valid;
     void* out16; float* out32; int ldo;
     const float* dot_w; float dot_b; float* dot_out;
+    // optional (C <= 512): the MX plane set of the output as a DT_MX consumer reads it (ConvGemmParams::mx_x4 ...): fp16 hi plane [rows][C], fp4 code
+    // planes of the hi / lo parts [rows][C / 2], their E8M0 scale planes [C / 128][mxo_qs_stride / 4 rows][4]; mxo_h == null: none
+    void* mxo_h; void* mxo_q4[2]; void* mxo_qs[2]; unsigned mxo_qs_stride;
 };
+// where a DT_MX call with an fp32 [M][K] input lays that input's plane set inside its mx_scratch (what launch_conv_gemm's own mx_planes_kernel pass fills):
+// a producer that writes these planes itself passes them as ConvGemmParams::A (= h, lda = K) / mx_x4 / mx_xs / mx_xs_stride instead of the fp32 tensor
+struct MxScratchPlanes { void* h; void* q4[2]; void* qs[2]; unsigned qs_stride; };
+MxScratchPlanes mx_scratch_planes(void* scratch, int M, int K);
 void launch_layernorm(const LayerNormParams& p, hipStream_t s);
 
 // token embedding gather + alpha * PE[pos] (reference model_open_source.py:107, encoder.py:257-261)

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "ev_kernels.h"
+#include "ev_mxq.h"
 
 namespace ev {
 
@@ -44,7 +45,19 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // reference modules/encoder.py:112-127 (eps = 1e-12); variance.py:29-33 (channel LN in predictors);
 // variance.py:46,119 (Linear(C,1) head fused as dot_w/dot_b).  One wave per row, C % 128 == 0; NV = float2 chunks per lane
 // (4: C <= 512, the acoustic model; 8: C <= 1024, the SimBERT encoder's 768).
-template <int NV>
+// PLANES: the output is (also) written as the MX plane set its DT_MX consumer reads (LayerNormParams::mxo_*: the mel decoder's QKV projection and conv-FFN
+// in the mx mode) -- bit for bit what mx_planes_kernel makes of the fp32 output, without that tensor pass: a lane's two channels are one byte of each code
+// plane (the four lanes of a quad gather theirs into one dword), a 32-channel block is one 16-lane DPP row (block maxima by quad / row-mirror permutes).
+__device__ __forceinline__ int dpp_quad_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_quad_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ float row16_max(float v) {          // maximum over the 16 lanes of a DPP row (v >= 0)
+    v = fmaxf(v, __int_as_float(dpp_quad_xor1(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_quad_xor2(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true)));      // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true)));      // row_mirror: the two halves
+    return v;
+}
+template <int NV, bool PLANES>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -88,6 +101,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
             }
             if (p.out32) *reinterpret_cast<float2*>(p.out32 + (long)row * p.ldo + c) = make_float2(y0, y1);
             if (p.out16) *reinterpret_cast<__half2*>(reinterpret_cast<__half*>(p.out16) + (long)row * p.ldo + c) = __floats2half2_rn(y0, y1);
+            if constexpr (PLANES) {
+                const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+                const float hf0 = (float)h0, hf1 = (float)h1, lf0 = y0 - hf0, lf1 = y1 - hf1;
+                const float mh = row16_max(fmaxf(fabsf(hf0), fabsf(hf1))), ml = row16_max(fmaxf(fabsf(lf0), fabsf(lf1)));
+                const unsigned bh = mx_scale_byte(mh), bl = mx_scale_byte(ml);
+                const float ih = __uint_as_float((254u - bh) << 23), il = __uint_as_float((254u - bl) << 23);
+                unsigned wh = (mx_fp4_code(hf0 * ih) | (mx_fp4_code(hf1 * ih) << 4)) << (8 * (lane & 3));
+                unsigned wl = (mx_fp4_code(lf0 * il) | (mx_fp4_code(lf1 * il) << 4)) << (8 * (lane & 3));
+                wh |= (unsigned)dpp_quad_xor1((int)wh); wh |= (unsigned)dpp_quad_xor2((int)wh);
+                wl |= (unsigned)dpp_quad_xor1((int)wl); wl |= (unsigned)dpp_quad_xor2((int)wl);
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<h2v*>(reinterpret_cast<_Float16*>(p.mxo_h) + (long)row * p.C + c) = h2v{h0, h1};
+                if ((lane & 3) == 0) {
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[0]) + (long)row * (p.C >> 1) + i * 64 + lane) = wh;
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mxo_q4[1]) + (long)row * (p.C >> 1) + i * 64 + lane) = wl;
+                }
+                if ((lane & 15) == 0) {
+                    const long so = (long)i * p.mxo_qs_stride + (long)row * 4 + (lane >> 4);
+                    reinterpret_cast<uint8_t*>(p.mxo_qs[0])[so] = (uint8_t)bh;
+                    reinterpret_cast<uint8_t*>(p.mxo_qs[1])[so] = (uint8_t)bl;
+                }
+            }
         }
     }
     if (p.dot_w) {
@@ -96,8 +131,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     }
 }
 void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
-    if (p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<4>), dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((layernorm_kernel<8>), dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    if (p.mxo_h && p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    else if (p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<4, false>), dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((layernorm_kernel<8, false>), dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------ SimBERT embeddings + pooler

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 2      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info */
+#define EV_ABI_VERSION 3      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info;
+                                 3: ev_config.mx_mrf / decoder_ln_planes, partial plane sets in ev_conv_gemm_desc (acc_h ..., mxo_partial) */
 
 typedef struct ev_handle ev_handle;
 
@@ -88,7 +89,12 @@ typedef struct ev_config {
                                    product, K / V tiles staged through LDS); 1 = exact fp32 MFMA kernel (the token-rate encoder's) */
     int32_t fused_pairs;        /* 0 (default) = fused ResBlock-pair kernels where they exist (C = 32 every k, C = 64 / k = 3 in fp16); 1 = every
                                    conv as its own launch (A/B switch, bit-identical in the fp16 mode) */
-    int32_t reserved[1];
+    int32_t mx_mrf;             /* EV_PREC_MX generator, stages with >= 128 channels: 0 (default) = the running MRF sum of a stage's three ResBlocks travels
+                                   as a partial plane set (fp16 hi plane + fp4 remainder codes + block scales: 2.53 instead of 4 bytes per element and
+                                   transfer, re-quantised once per ResBlock; emulated cost 5e-6 of waveform error); 1 = an fp32 running sum */
+    int32_t decoder_ln_planes;  /* EV_PREC_MX decoder: 0 (default) = the LayerNorms in front of the QKV projection and the conv-FFN write the plane sets those
+                                   layers read (no fp32 copy, no separate quantisation pass; the same bits); 1 = fp32 output + a planes pass */
+    int32_t reserved[2];
 } ev_config;
 
 /* Precision of the frame-rate path.  F16: fp16 MFMA operands (what BASELINE.json's bf16 / fp16 configs name).

@@ -52,6 +52,10 @@ typedef struct ev_conv_gemm_desc {
        res_x4 = the fp4 codes of the remainder [M][N / 2], res_xs their E8M0 scales [N / 128][res_xs_stride / 4][4]; x = hi + code * scale,
        negative values times res_inv_slope */
     const void* res_x4; const void* res_xs; unsigned res_xs_stride; float res_inv_slope;
+    /* accumulate-in from a partial plane set (dtype 3 with res_dtype 3; instead of acc32): acc_h fp16 hi plane [M][N] (ldacc == N), acc_x4 fp4 codes of the
+       remainder [M][N / 2], acc_xs their E8M0 scales [N / 128][acc_xs_stride / 4][4]; the addend is hi + code * scale.  mxo_partial != 0: the output plane
+       set is partial as well (mxo_h, mxo_q4[1], mxo_qs[1] only; mxo_slope = 1), and may alias the acc_* planes */
+    const void* acc_h; const void* acc_x4; const void* acc_xs; unsigned acc_xs_stride; int mxo_partial;
 } ev_conv_gemm_desc;
 
 int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* hip_stream);
@@ -89,6 +93,13 @@ int ev_op_resblock_pair_c64(const ev_res_pair_desc* d, void* hip_stream);
 int ev_op_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
                     const uint8_t* row_valid, void* out16, float* out32, const float* dot_w, float dot_b,
                     float* dot_out, void* hip_stream);
+
+/* The same LayerNorm writing the MX plane set of its output (emotivoice_amd/mxfp4.py) instead of fp32 rows: h fp16 hi plane [rows][C], q4h / q4l the fp4
+ * codes of the hi / lo parts [rows][C / 2], qsh / qsl their E8M0 block scales [C / 128][qs_stride / 4 rows][4]; C <= 512, C % 128 == 0.  What the mel
+ * decoder's QKV projection / conv-FFN read in the mx mode (reference modules/encoder.py:154-200: the norm in front of each sub-layer). */
+int ev_op_layernorm_planes(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
+                           const uint8_t* row_valid, void* h, void* q4h, void* q4l, void* qsh, void* qsl,
+                           unsigned qs_stride, void* hip_stream);
 
 /* Multi-head self-attention restricted to each utterance's rows (reference modules/encoder.py:72-109).
  * is_f16: 1 = fp16 rows (fp16 MFMA flash kernel), 0 = fp32 rows, exact fp32 MFMA products, 2 = fp32 rows, split-precision products

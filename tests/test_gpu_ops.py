@@ -1302,3 +1302,108 @@ def test_mx_residual_from_planes(lib, Cc, k, dil, mode):
             rec = ps_o.h[PAD:PAD + M].float().cpu().double() + torch.from_numpy(lo_rec).double()
             assert _rel(rec, _lrelu(ref, 0.1)) < 1e-4, (Cc, k, dil, mode, _rel(rec, _lrelu(ref, 0.1)))
             assert not ps_o.h[PAD:PAD + M].cpu().numpy()[~vrow.numpy()].any()
+
+
+@pytest.mark.parametrize("Cc,k,dil,mode", [(128, 3, 1, "part"), (128, 7, 3, "acc+part"), (128, 11, 1, "acc>planes"), (256, 3, 5, "part"),
+                                           (256, 7, 1, "acc+part"), (256, 11, 1, "acc>planes")])
+def test_mx_mrf_partial_plane_sets(lib, Cc, k, dil, mode):
+    """The running MRF sum of a generator stage as PARTIAL plane sets (ev_conv_gemm_desc::acc_h / mxo_partial; conv_gemm_mx_kernel's EPI_ACCPL / EPI_PART
+    epilogues): "part" = the first ResBlock's last conv writes out_scale * x as fp16 hi plane + fp4 remainder codes + their scales, "acc+part" = the second
+    one adds the partial and rewrites it IN PLACE, "acc>planes" = the third one adds it and writes the next up-conv's full plane set.  Each is compared bit
+    for bit with the fp32 flow it replaces: the same launch with out32 (and the partial's fp32 value as acc32) followed by the host quantiser."""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(1300 + Cc + k + dil)
+    M = 256 * 5
+    R = M + 2 * PAD
+    valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
+    valid[:3] = 0
+    valid[90:92] = 0
+    vrow = valid.repeat_interleave(8).bool().cpu()
+    xt = torch.randn(R, Cc) * torch.exp(0.5 * torch.randn(R, 1))
+    xt[:PAD] = 0
+    xt[PAD + M:] = 0
+    x = torch.randn(R, Cc) * torch.exp(0.5 * torch.randn(R, 1))
+    ps_t, _ = _host_plane_set(xt)
+    ps_x, _ = _host_plane_set(_lrelu(x, 0.1).float())
+    run = (torch.randn(R, Cc) * torch.exp(0.7 * torch.randn(R, 1))).float()            # the running sum so far (raw values, no activation)
+    ps_s, (sh64, _, sql64) = _host_plane_set(run)
+    acc_val = (sh64.float() + sql64.float())[PAD:PAD + M].contiguous().cuda()           # fp32(hi) + fp32(Q4(lo)) in fp32: what the epilogue adds
+    w = torch.randn(Cc, Cc, k) / math.sqrt(Cc * k)
+    bias = torch.randn(Cc, device="cuda") * 0.1
+    wg = w.permute(0, 2, 1).contiguous().numpy()
+    hi = wg.astype(np.float16)
+    lo16 = ((wg - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    planes = mxfp4.pack_weight_planes(wg)
+    d_hi, d_lo, d_mx = torch.from_numpy(hi).cuda(), torch.from_numpy(lo16).cuda(), torch.from_numpy(planes).cuda()
+    acc_in, part = mode.startswith("acc"), mode.endswith("part")
+
+    def desc():
+        d = _ffi.ev_conv_gemm_desc()
+        d.dtype, d.W, d.W_lo, d.W_mx = 3, d_hi.data_ptr(), d_lo.data_ptr(), d_mx.data_ptr()
+        ps_t.in_fields(d)
+        d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale, d.ldo = bias.data_ptr(), M, Cc, Cc, k, dil, (k - 1) // 2, 1.0 / 3.0, Cc
+        d.row_valid, d.valid_shift = valid.data_ptr(), 3
+        d.res, d.res_dtype, d.ldres = ps_x.h[PAD:].data_ptr(), 3, Cc
+        d.res_x4, d.res_xs, d.res_xs_stride, d.res_inv_slope = ps_x.q4[1][PAD:].data_ptr(), ps_x.qs[1][0, PAD:].data_ptr(), R * 4, 10.0
+        return d
+
+    # the fp32 flow: the same conv with an fp32 output (and the partial's value as an fp32 accumulate-in)
+    out = torch.full((M, Cc), 7.0, device="cuda")
+    d = desc()
+    d.out32 = out.data_ptr()
+    if acc_in:
+        d.acc32, d.ldacc = acc_val.data_ptr(), Cc
+    _launch(lib, d)
+    assert float(out[~vrow.cuda()].abs().max()) == 0.0
+    # the plane flow
+    d = desc()
+    ps_o = ps_s if mode == "acc+part" else _PlaneSet(M, Cc)                              # in place for the second ResBlock
+    untouched = [ps_o.q4[0].clone(), ps_o.qs[0].clone()]
+    if acc_in:
+        d.acc_h, d.acc_x4, d.acc_xs, d.acc_xs_stride, d.ldacc = ps_s.h[PAD:].data_ptr(), ps_s.q4[1][PAD:].data_ptr(), ps_s.qs[1][0, PAD:].data_ptr(), R * 4, Cc
+    ps_o.out_fields(d, 1.0 if part else 0.1)
+    d.mxo_partial = 1 if part else 0
+    _launch(lib, d)
+    _, _, _, (h16o, cho, clo, sho, slo) = _mx_act_parts(out.cpu() if part else _lrelu(out.cpu(), 0.1))
+    sl_ = lambda q: q[:, PAD:PAD + M].permute(1, 0, 2).reshape(M, Cc // 32)             # noqa: E731
+    assert np.array_equal(ps_o.h[PAD:PAD + M].cpu().numpy().view(np.uint16), h16o.view(np.uint16)), mode
+    assert np.array_equal(ps_o.q4[1][PAD:PAD + M].cpu().numpy(), clo) and np.array_equal(sl_(ps_o.qs[1]).cpu().numpy(), slo), mode
+    if part:            # a partial set has no hi-code plane: those buffers are not written
+        assert torch.equal(ps_o.q4[0], untouched[0]) and torch.equal(ps_o.qs[0], untouched[1])
+    else:
+        assert np.array_equal(ps_o.q4[0][PAD:PAD + M].cpu().numpy(), cho) and np.array_equal(sl_(ps_o.qs[0]).cpu().numpy(), sho)
+    # and a third launch reproduces the second bit for bit (in-place launches start from a fresh copy of the partial)
+    if mode != "acc+part":
+        ps_2 = _PlaneSet(M, Cc)
+        ps_2.out_fields(d, 1.0 if part else 0.1)
+        _launch(lib, d)
+        assert torch.equal(ps_2.h[PAD:PAD + M], ps_o.h[PAD:PAD + M]) and torch.equal(ps_2.q4[1][PAD:PAD + M], ps_o.q4[1][PAD:PAD + M])
+
+
+def test_layernorm_writes_its_consumers_plane_set(lib):
+    """LayerNorm with a plane-set output (ev_op_layernorm_planes; the mel decoder's LayerNorms in the mx mode) = the fp32 LayerNorm followed by the host
+    quantiser, bit for bit; invalid rows give all-zero planes."""
+    torch.manual_seed(77)
+    rows, Cc = 1024 + 3, 384
+    x = (torch.randn(rows, Cc, device="cuda") * torch.exp(0.5 * torch.randn(rows, 1, device="cuda")) + 0.3)
+    g, b = torch.randn(Cc, device="cuda") * 0.5 + 1.0, torch.randn(Cc, device="cuda") * 0.2
+    valid = torch.ones(rows, dtype=torch.uint8, device="cuda")
+    valid[:4] = 0
+    valid[500:504] = 0
+    y = torch.full((rows, Cc), 9.0, device="cuda")
+    assert lib.ev_op_layernorm(x.data_ptr(), rows, Cc, g.data_ptr(), b.data_ptr(), 1e-12, valid.data_ptr(), None, y.data_ptr(), None, 0.0, None, None) == 0
+    R = rows + 2 * PAD
+    hpl = torch.full((R, Cc), 3.0, device="cuda", dtype=torch.float16)
+    q4 = [torch.full((R, Cc // 2), 0x77, device="cuda", dtype=torch.uint8) for _ in range(2)]
+    qs = [torch.full((Cc // 128, R, 4), 130, device="cuda", dtype=torch.uint8) for _ in range(2)]
+    assert lib.ev_op_layernorm_planes(x.data_ptr(), rows, Cc, g.data_ptr(), b.data_ptr(), 1e-12, valid.data_ptr(), hpl[PAD:].data_ptr(),
+                                      q4[0][PAD:].data_ptr(), q4[1][PAD:].data_ptr(), qs[0][0, PAD:].data_ptr(), qs[1][0, PAD:].data_ptr(), R * 4, None) == 0
+    torch.cuda.synchronize()
+    _, _, _, (h16, ch, cl, sh, sl) = _mx_act_parts(y.cpu())
+    assert np.array_equal(hpl[PAD:PAD + rows].cpu().numpy().view(np.uint16), h16.view(np.uint16))
+    sl_ = lambda q: q[:, PAD:PAD + rows].permute(1, 0, 2).reshape(rows, Cc // 32)      # noqa: E731
+    for i, (codes, sb) in enumerate(((ch, sh), (cl, sl))):
+        assert np.array_equal(q4[i][PAD:PAD + rows].cpu().numpy(), codes), i
+        assert np.array_equal(sl_(qs[i]).cpu().numpy(), sb), i
+    assert not hpl[PAD:PAD + rows].cpu().numpy()[~valid.bool().cpu().numpy()].any()
+    assert float(hpl[:PAD].float().min()) == 3.0 and float(hpl[PAD + rows:].float().max()) == 3.0            # slack rows untouched

@@ -63,12 +63,14 @@ def mx_quant(v, fmt, dim):
 
 class Recipe:
     def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None, mrf16=False,
-                 engine_flow=False):
+                 engine_flow=False, mrf_planes=None):
         self.name, self.cross, self.res32, self.op32, self.lo_terms = name, cross, res32, op32, lo_terms
         # mrf16: the first two scaled ResBlock outputs of a stage are stored in fp16 and added in the third one's fp32 epilogue (the fast mode's MRF sum:
         # 8 bytes less HBM traffic per stage-output element than an fp32 running sum)
         # engine_flow: the engine's actual data flow -- stage 3 (C = 32) keeps fp32 in / out (fused pairs), conv_pre's output is fp32 (planes are cut from it)
         self.mrf16, self.engine_flow = mrf16, engine_flow
+        # mrf_planes: the first two scaled ResBlock outputs of a stage stored as fp16 hi + remainder codes in this MX format (2.53 bytes per element)
+        self.mrf_planes = mrf_planes
         # res_planes: the residual stream exists ONLY as the plane set of leaky_relu(x, .1) its consumers read anyway: fp16 hi plane + the
         # remainder in this format ("f16" = a second fp16 plane, "fp4" / "fp6" = the MX code plane itself); None = a separate fp32 tensor
         self.res_planes = res_planes
@@ -136,6 +138,9 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
             y = y / nk
             if rc.mrf16 and j + 1 < nk:
                 y = r16(y)
+            if rc.mrf_planes and j + 1 < nk:          # partial sums as fp16 hi + MX remainder codes (no leaky-relu: the raw scaled branch)
+                hq = r16(y)
+                y = hq + mx_quant(y - hq, rc.mrf_planes, 1)
             xs = y if xs is None else xs + y
         x = st(xs)
     x = F.leaky_relu(x)
@@ -190,6 +195,8 @@ def main():
             Recipe("ENGINE r4: MX-fp4, residual from fp4 planes (stages 0-2), fp32 stage 3", "fp4", res_planes="fp4", engine_flow=True),
             Recipe("ENGINE r4 + fp16 MRF partial sums", "fp4", res_planes="fp4", engine_flow=True, mrf16=True),
             Recipe("MX-fp4, fp32 residual + fp16 MRF partial sums", "fp4", mrf16=True),
+            Recipe("ENGINE r4 + MRF partials as hi + fp4 remainder", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4"),
+            Recipe("ENGINE r4 + MRF partials as hi + fp4 remainder, stage 3 from planes too", "fp4", res_planes="fp4", mrf_planes="fp4"),
             Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
             Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
         ]
