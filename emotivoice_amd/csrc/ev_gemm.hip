@@ -387,12 +387,20 @@ __device__ __forceinline__ long uniform64(long v) {
 }
 __device__ uint8_t g_row_always_valid[4] = {1, 1, 1, 1};   // not const: a constant-address-space object would turn the select below into FLAT loads
 
-template <int MT, int NT, int EPI>
+// RP = rows per transposing pass: 32 (scratch of 32 padded rows = 8.5 KB per wave, aliasing the staging buffers) or 16 (the persistent MX kernel: 4 KB per
+// wave, 256-byte rows with an XOR swizzle of the 16-byte column -- conflict-free for the ds_write_b128 / ds_read_b128 lane groups of MI355X_MICROARCH.md --
+// which leaves one slab buffer and three ring slots free for the next tile's first requests while this one drains).  Same values, same order per element.
+template <int MT, int NT, int EPI, int RP = 32>
 __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x4 (&acc)[NT][MT], char* wave_lds, int t0, int co0 EV_TRACE_EPI_PARAMS) {
     constexpr int TC = NT * 16;
-    constexpr int PITCH = epi_pitch<TC>();
-    constexpr int LPR = TC / 8, RPI = 64 / LPR, IT = 32 / RPI, NP = MT / 2;
-    const int lane = threadIdx.x & 63;
+    constexpr bool SWZ = RP == 16;
+    constexpr int PITCH = SWZ ? TC * 4 : epi_pitch<TC>();
+    constexpr int LPR = TC / 8, RPI = 64 / LPR, IT = RP / RPI, NP = MT * 16 / RP, NG = MT / 2;
+    static_assert((RP == 32 || (RP == 16 && TC == 64)) && IT >= 1, "rows per pass");
+    int lane_ = threadIdx.x & 63;
+    if constexpr (SWZ) asm volatile("" : "+v"(lane_));          // (called once per tile of a persistent block: nothing lane-derived may become an invariant of the tile
+                                                                //  loop, or it is live through the K loop -- spilled registers, reloaded behind an s_waitcnt vmcnt(0))
+    const int lane = lane_;
     const int fr = lane & 15, fq = lane >> 4;
     const int rr = lane / LPR, g = lane % LPR;
     const int co = co0 + g * 8;
@@ -408,9 +416,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     // one byte load per 32-row pass (lane l <-> row l & 31), turned into a wave-uniform bit mask by a ballot: no VGPRs held
     const uint8_t* vptr = p.row_valid ? p.row_valid : g_row_always_valid;
     const int vshift = p.row_valid ? p.valid_shift : 31;
-    uint8_t vld[NP];
+    uint8_t vld[NG];
 #pragma unroll
-    for (int pass = 0; pass < NP; ++pass) vld[pass] = vptr[(t0 + pass * 32 + (lane & 31)) >> vshift];
+    for (int pass = 0; pass < NG; ++pass) vld[pass] = vptr[(t0 + pass * 32 + (lane & 31)) >> vshift];
     uint4 r16[2][IT], a16[2][IT][2];
     float4 r32[2][IT][2], a32[2][IT][2];
     uint4 rph[2][IT];                       // EPI_RESPL: 8 fp16 hi parts, 8 fp4 remainder codes, the block's scale byte
@@ -432,10 +440,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
         ap_sl0 = (unsigned)(so - uniform64(so));
     }
     constexpr bool LEAN = (EPI & EPI_LEAN) != 0;
+    // byte offset of 16-byte half H of the lane's 8 channels in transposed row IT_ * RPI + rr of the scratch
+#define EV_EPI_RD(IT_, H) (SWZ ? ((IT_) * RPI + rr) * PITCH + (((2 * g + (H)) ^ (((IT_) * RPI + rr) & 15)) << 4) : ((IT_) * RPI + rr) * PITCH + g * 32 + (H) * 16)
 #define EV_EPI_SET(PASS) (LEAN ? 0 : ((PASS) & 1))
 #define EV_EPI_PREFETCH(PASS)                                                                                              \
     _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                                                    \
-        const long tu_ = t0u + (PASS) * 32 + it * RPI;                                                                     \
+        const long tu_ = t0u + (PASS) * RP + it * RPI;                                                                     \
         if constexpr (EPI & EPI_RES16)                                                                                     \
             r16[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.res) + (tu_ * p.ldres + co0u) * 2) + vlane(b_res16)); \
         if constexpr (EPI & EPI_RES32) {                                                                                   \
@@ -447,13 +457,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             const long ulin_ = tu_ * p.ldres + co0u;                                                                       \
             rph[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.res) + ulin_ * 2) + vlane(b_res16));  \
             rpc[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const unsigned*>(uptr(reinterpret_cast<const char*>(p.res_x4) + (ulin_ >> 1)) + vlane(b_resq)); \
-            rps[EV_EPI_SET(PASS)][it] = uptr(reinterpret_cast<const uint8_t*>(p.res_xs) + (rp_su + ((PASS) * 32 + it * RPI) * 4))[vlane(rp_sl0)]; \
+            rps[EV_EPI_SET(PASS)][it] = uptr(reinterpret_cast<const uint8_t*>(p.res_xs) + (rp_su + ((PASS) * RP + it * RPI) * 4))[vlane(rp_sl0)]; \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ACCPL) {                                                                                   \
             const long ulin_ = tu_ * p.ldacc + co0u;                                                                       \
             aph[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const uint4*>(uptr(reinterpret_cast<const char*>(p.acc_h) + ulin_ * 2) + vlane(b_acc16));  \
             apc[EV_EPI_SET(PASS)][it] = *reinterpret_cast<const unsigned*>(uptr(reinterpret_cast<const char*>(p.acc_x4) + (ulin_ >> 1)) + vlane(b_accq)); \
-            aps[EV_EPI_SET(PASS)][it] = uptr(reinterpret_cast<const uint8_t*>(p.acc_xs) + (ap_su + ((PASS) * 32 + it * RPI) * 4))[vlane(ap_sl0)]; \
+            aps[EV_EPI_SET(PASS)][it] = uptr(reinterpret_cast<const uint8_t*>(p.acc_xs) + (ap_su + ((PASS) * RP + it * RPI) * 4))[vlane(ap_sl0)]; \
         }                                                                                                                  \
         if constexpr (EPI & EPI_ACC32) {                                                                                   \
             const char* ap_ = uptr(reinterpret_cast<const char*>(p.acc32) + (tu_ * p.ldacc + co0u) * 4) + vlane(b_acc);    \
@@ -466,9 +476,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
         }                                                                                                                  \
     }
     if constexpr (!LEAN) { EV_EPI_PREFETCH(0) }
-    unsigned vmask[NP];
+    unsigned vmask[NG];
 #pragma unroll
-    for (int pass = 0; pass < NP; ++pass) vmask[pass] = (unsigned)__builtin_amdgcn_ballot_w64(vld[pass] != 0);
+    for (int pass = 0; pass < NG; ++pass) vmask[pass] = (unsigned)__builtin_amdgcn_ballot_w64(vld[pass] != 0);
 
     // The per-element VALU work bounds this epilogue (timeline: ~100 VALU per 8 outputs took ~800 cycles per iteration with or
     // without the stores), so everything is kept in packed-fp32 pairs (v_pk_add / v_pk_mul), leaky-relu is max(v, slope * v)
@@ -495,9 +505,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     float* const o32a = p.out32_before_post ? p.out32 : nullptr;
     float* const o32b = p.out32_before_post ? nullptr : p.out32;
     const long rowoff_u = (long)t0u * p.ldo + co0u;             // uniform part of the output offsets; the lane part is l_o
-    unsigned lrbit[IT];
+    unsigned lrbit[32 / RPI];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) lrbit[it] = 1u << (it * RPI + rr);
+    for (int it = 0; it < 32 / RPI; ++it) lrbit[it] = 1u << (it * RPI + rr);
     // plane-set output: the lane's scale byte moves by a fixed distance per output row (ldo == N is a multiple of the plane set's C, so a
     // step of one [M][N] row is N / C whole plane-set rows and the channel block stays the lane's own)
     long mx_su = 0;
@@ -518,11 +528,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     for (int pass = 0; pass < NP; ++pass) {
         __builtin_amdgcn_wave_barrier();
         if constexpr (LEAN) { EV_EPI_PREFETCH(pass) }
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+        if constexpr (SWZ) {
 #pragma unroll
             for (int a = 0; a < NT; ++a)
-                *reinterpret_cast<f32x4*>(wave_lds + (bb * 16 + fr) * PITCH + (a * 16 + 4 * fq) * 4) = acc[a][pass * 2 + bb];
+                *reinterpret_cast<f32x4*>(wave_lds + fr * PITCH + (((a * 4 + fq) ^ fr) << 4)) = acc[a][pass];
+        } else {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+                    *reinterpret_cast<f32x4*>(wave_lds + (bb * 16 + fr) * PITCH + (a * 16 + 4 * fq) * 4) = acc[a][pass * 2 + bb];
+        }
         __builtin_amdgcn_wave_barrier();
         if constexpr (!LEAN) { if (pass + 1 < NP) { EV_EPI_PREFETCH(pass + 1) } }
         EV_STAMP()
@@ -530,17 +546,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
         if constexpr (!LEAN) {
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32);
-                lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32 + 16);
+                lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + EV_EPI_RD(it, 0));
+                lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + EV_EPI_RD(it, 1));
             }
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             if constexpr (LEAN) {         // (row by row: 8 registers instead of 8 * IT)
-                lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32);
-                lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + (it * RPI + rr) * PITCH + g * 32 + 16);
+                lv[it][0] = *reinterpret_cast<const f32x4*>(wave_lds + EV_EPI_RD(it, 0));
+                lv[it][1] = *reinterpret_cast<const f32x4*>(wave_lds + EV_EPI_RD(it, 1));
             }
-            const long off_u = rowoff_u + (long)(pass * 32 + it * RPI) * p.ldo;
+            const long off_u = rowoff_u + (long)(pass * RP + it * RPI) * p.ldo;
             const f32x4 v0 = lv[it][0], v1 = lv[it][1];
             f32x2 v[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
 #pragma unroll
@@ -610,8 +626,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             }
             // rows outside the utterances give zeros in every output (leaky-relu and the conversions keep +0): masked once, and only in a
             // 32-row group that has such rows at all (wave-uniform; VALU only, so no store count depends on it)
-            if (vmask[pass] != 0xffffffffu) {
-                const bool valid = (vmask[pass] & lrbit[it]) != 0u;
+            if (vmask[pass * RP / 32] != 0xffffffffu) {
+                const bool valid = (vmask[pass * RP / 32] & lrbit[(pass * RP % 32) / RPI + it]) != 0u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j][0] = valid ? v[j][0] : 0.f; v[j][1] = valid ? v[j][1] : 0.f; }
             }
@@ -646,13 +662,14 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
                     for (int j = 0; j < 4; ++j) am[j] = lrelu2(v[j], mxo_slope2);
                 }
-                mx_emit_planes<(EPI & EPI_PART) != 0>(p, am, off_u, l_o0, mx_su + (long)((pass * 32 + it * RPI) * mx_sstep), mx_sl, lane);
+                mx_emit_planes<(EPI & EPI_PART) != 0>(p, am, off_u, l_o0, mx_su + (long)((pass * RP + it * RPI) * mx_sstep), mx_sl, lane);
             }
             EV_STAMP()
         }
     }
 #undef EV_EPI_PREFETCH
 #undef EV_EPI_SET
+#undef EV_EPI_RD
 }
 
 // ---- main kernel.  LDS: 64-byte pitch with an XOR swizzle (16-B part ^= (row >> 1) & 3): conflict-free ds_read_b128 for

@@ -112,6 +112,11 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const int wt = wave & 3, wc = wave >> 2;          // wc is also the phase group: waves w and w + 4 share a SIMD
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
+    // (Round 4 tried a persistent tile loop here, twice.  Second form: the next tile's first six requests and its row_valid look-up issued between a tile's last
+    // barrier and its epilogue, 16-row swizzled epilogue scratch beside them: bit-identical, 3-5 % SLOWER in every shape, with or without the early requests,
+    // with or without a staggered start of a CU's two blocks (profiles/r4_e_mx_persistent_prefetch_ab.txt).  A wave's vmcnt is one in-order FIFO of its loads AND
+    // stores: a wave that has just issued a tile's stores cannot wait for any newer request without draining them, while a fresh block starts with an empty FIFO
+    // behind the retired block's draining stores.  The dispatcher's back-filling IS the overlap.  First form:)
     // (Round 4 tried a persistent tile loop here -- min(tiles, 2 x CUs) blocks walking the tile list with stride gridDim.x, bit-identical results --
     // to save the ~5 us per residency round that a tile costs outside its K loop and epilogue (profiles/r3_k_mx_gemm_ablation.txt).  Measured
     // in one process against one block per tile (profiles/r4_b_mx_persistent_ab.txt): 0-5 % SLOWER on every stage-0 / stage-1 shape.  The hardware's
@@ -331,7 +336,9 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC);
     else {
         EV_TRACE_EPI_DUMMY
-        gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC EV_TRACE_EPI_ARGS);
+        // 16-row transposing passes through 4 KB of XOR-swizzled scratch per wave: 0-3 % faster than the 32-row padded form and 6-21 fewer live registers
+        // in the residual-from-planes variants -- every instantiation compiles without spills (profiles/r4_e_mx_persistent_prefetch_ab.txt, dbg 72)
+        gemm_epilogue_fast<MT, NT, EPI, 16>(p, acc, smem + wave * 4096, m0 + wt * 64, n0 + wc * TC EV_TRACE_EPI_ARGS);
     }
 }
 

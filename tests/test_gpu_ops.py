@@ -798,6 +798,116 @@ def test_mx_conv_gemm_long_tile_list_with_all_gap_tiles(lib, Cc, N, k, dil, tile
     assert _rel(o0[lo:hi].cpu().double(), emu) < 2e-6
 
 
+def _random_plane_set(M, Cc, seed):
+    """a device plane set with random contents (hi parts ~N(0, 1) with a per-row gain, random fp4 codes, block scales around 2^-8 .. 2^-2 of the hi parts):
+    for A/B comparisons of two kernels on identical inputs, no host quantiser involved."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ps = _PlaneSet(M, Cc)
+    R = ps.R
+    ps.h = (torch.randn(R, Cc, device="cuda", generator=g) * torch.exp(0.5 * torch.randn(R, 1, device="cuda", generator=g))).half()
+    ps.q4 = [torch.randint(0, 256, (R, Cc // 2), device="cuda", dtype=torch.uint8, generator=g) for _ in range(2)]
+    ps.qs = [torch.randint(lo, lo + 4, (max(1, Cc // 128), R, 4), device="cuda", dtype=torch.uint8, generator=g) for lo in (124, 113)]
+    for t in (ps.h, ps.q4[0], ps.q4[1]):
+        t[:PAD] = 0
+        t[PAD + M:] = 0
+    return ps
+
+
+MX_EPI_FORMS = ["conv1", "gelu", "o32", "o32+planes", "res32", "res32+acc", "respl", "respl+o32", "respl+acc+o32+planes", "respl+acc>planes",
+                    "part", "acc+part", "accpl>planes"]
+
+
+@pytest.mark.parametrize("Cc,k,dil,tiles_m", [(128, 3, 1, 520), (128, 7, 3, 515), (128, 11, 5, 513), (256, 3, 5, 260), (256, 11, 1, 257)])
+def test_mx_epilogue_forms_long_tile_list_deterministic(lib, Cc, k, dil, tiles_m):
+    """conv_gemm_mx_kernel in every fast epilogue form the engine uses, on more tiles than the chip holds at once, random plane sets with invalid row groups incl.
+    whole all-gap tiles: two launches agree on every output bit for bit (a missing MFMA -> VALU wait state or a scratch race shows up as run-to-run noise: round 4's
+    mfma_asm_fence finding), invalid rows are zeros in every output.  (Written as the A/B harness of the persistent-tile-loop experiment, which it passed bit for
+    bit against this kernel: profiles/r4_e_mx_persistent_prefetch_ab.txt.)"""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(1700 + Cc + k)
+    M = 256 * tiles_m
+    R = M + 2 * PAD
+    assert (M // 256) * (Cc // 128) > 512
+    w = torch.randn(Cc, Cc, k) / math.sqrt(Cc * k)
+    wg = w.permute(0, 2, 1).contiguous().numpy()
+    hi = wg.astype(np.float16)
+    lo16 = ((wg - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    d_hi, d_lo, d_mx = torch.from_numpy(hi).cuda(), torch.from_numpy(lo16).cuda(), torch.from_numpy(mxfp4.pack_weight_planes(wg)).cuda()
+    bias = torch.randn(Cc, device="cuda") * 0.1
+    valid = torch.ones(M // 64, dtype=torch.uint8, device="cuda")
+    valid[:5] = 0                               # the first tile is all gap, the second starts with one
+    valid[1000:1013] = 0                        # three whole tiles and a partial one in the middle
+    valid[-9:] = 0                              # the last two tiles
+    ps_in, ps_res, ps_acc = _random_plane_set(M, Cc, 1), _random_plane_set(M, Cc, 2), _random_plane_set(M, Cc, 3)
+    res32 = torch.randn(M, Cc, device="cuda")
+    acc32 = torch.randn(M, Cc, device="cuda")
+    for form in MX_EPI_FORMS:
+        outs = []
+        for dbg in (0, 0):
+            d = _ffi.ev_conv_gemm_desc()
+            d.dtype, d.W, d.W_lo, d.W_mx = 3, d_hi.data_ptr(), d_lo.data_ptr(), d_mx.data_ptr()
+            ps_in.in_fields(d)
+            d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale, d.ldo = bias.data_ptr(), M, Cc, Cc, k, dil, (k - 1) // 2, 1.0, Cc
+            d.row_valid, d.valid_shift = valid.data_ptr(), 6
+            out = torch.full((M, Cc), 7.0, device="cuda")
+            ps_o = _PlaneSet(M, Cc)
+            acc_ps = None
+            if form == "conv1":
+                d.act, d.act_slope = 3, 0.1
+                ps_o.out_fields(d, 1.0)
+            elif form == "gelu":
+                d.act = 2
+                ps_o.out_fields(d, 1.0)
+            elif form in ("o32", "o32+planes"):
+                d.out32 = out.data_ptr()
+                if "planes" in form:
+                    ps_o.out_fields(d, 0.1)
+            elif form.startswith("res32"):
+                d.res, d.res_dtype, d.ldres, d.out32, d.out_scale = res32.data_ptr(), 1, Cc, out.data_ptr(), 1.0 / 3.0
+                ps_o.out_fields(d, 0.1)
+                if "acc" in form:
+                    out.copy_(acc32)
+                    d.acc32, d.ldacc = out.data_ptr(), Cc                   # in place, as the engine's fp32 MRF sum
+            else:
+                d.res, d.res_dtype, d.ldres, d.out_scale = ps_res.h[PAD:].data_ptr(), 3, Cc, 1.0 / 3.0
+                d.res_x4, d.res_xs, d.res_xs_stride, d.res_inv_slope = ps_res.q4[1][PAD:].data_ptr(), ps_res.qs[1][0, PAD:].data_ptr(), R * 4, 10.0
+                if form == "respl":
+                    ps_o.out_fields(d, 0.1)
+                elif form == "respl+o32":
+                    d.out32 = out.data_ptr()
+                elif form == "respl+acc+o32+planes":
+                    d.acc32, d.ldacc, d.out32 = acc32.data_ptr(), Cc, out.data_ptr()
+                    ps_o.out_fields(d, 0.1)
+                elif form == "respl+acc>planes":
+                    d.acc32, d.ldacc = acc32.data_ptr(), Cc
+                    ps_o.out_fields(d, 0.1)
+                elif form == "part":
+                    ps_o.out_fields(d, 1.0)
+                    d.mxo_partial = 1
+                else:
+                    acc_ps = _PlaneSet(M, Cc)
+                    acc_ps.h.copy_(ps_acc.h); acc_ps.q4[1].copy_(ps_acc.q4[1]); acc_ps.qs[1].copy_(ps_acc.qs[1])
+                    d.acc_h, d.acc_x4, d.acc_xs, d.acc_xs_stride, d.ldacc = acc_ps.h[PAD:].data_ptr(), acc_ps.q4[1][PAD:].data_ptr(), acc_ps.qs[1][0, PAD:].data_ptr(), R * 4, Cc
+                    if form == "acc+part":
+                        ps_o = acc_ps                                       # in place, as the engine's second ResBlock
+                        ps_o.out_fields(d, 1.0)
+                        d.mxo_partial = 1
+                    else:
+                        ps_o.out_fields(d, 0.1)
+            d.reserved0 = dbg
+            _launch(lib, d)
+            outs.append((out, ps_o))
+        (o0, p0), (o1, p1) = outs
+        assert torch.equal(o0, o1), form
+        assert torch.equal(p0.h, p1.h) and all(torch.equal(p0.q4[i], p1.q4[i]) and torch.equal(p0.qs[i], p1.qs[i]) for i in range(2)), form
+        wrote32 = form not in ("conv1", "gelu", "respl", "respl+acc>planes", "part", "acc+part", "accpl>planes")
+        if wrote32:
+            vrow = valid.bool().repeat_interleave(64)
+            assert float(o0[~vrow].abs().max()) == 0.0 and float(o0[vrow].abs().max()) > 0.1, form
+        else:
+            assert float(p0.h[PAD:PAD + M].float().abs().max()) > 0.1 and not bool(p0.h[PAD:PAD + 5 * 64].any()), form
+
+
 @pytest.mark.parametrize("Cc,k,dil,up", [(128, 7, 3, 0), (256, 3, 1, 0), (128, 11, 5, 0), (256, 3, 1, 4)])
 def test_mx_plane_set_chain(lib, Cc, k, dil, up):
     """The producer's epilogue writes the consumer's operand planes (EPI_MXP): (1) the planes equal the host quantiser applied to
