@@ -41,7 +41,7 @@ def main():
         s = [torch.full((nch, R, 4), 120, device="cuda", dtype=torch.uint8) for _ in range(2)]
         return h, q, s
 
-    xi, xo = plane_set(), plane_set()
+    xi, xo, xr = plane_set(), plane_set(), plane_set()
     res = torch.randn(M, Cc, device="cuda", generator=g)
     out = torch.empty(M, Cc, device="cuda")
     bias = torch.zeros(Cc, device="cuda")
@@ -54,7 +54,7 @@ def main():
         wg = (np.random.default_rng(k).standard_normal((Cc, k, Cc)) / np.sqrt(Cc * k)).astype(np.float32)
         d_hi = torch.from_numpy(wg.astype(np.float16)).cuda()
         d_mx = torch.from_numpy(mxfp4.pack_weight_planes(wg)).cuda()
-        for form in ("conv1", "conv2"):
+        for form in ("conv1", "conv2", "conv2pl"):
             for abl, nm in list(names.items()) + [(0, "full (again)")] + [(-1 - v, "dbg %d" % v) for v in dbgs]:          # (the first timing of a weight set runs 5-15 % slow: clocks)
                 d = _ffi.ev_conv_gemm_desc()
                 h, q, s = xi
@@ -68,6 +68,10 @@ def main():
                 d.mxo_qs[0], d.mxo_qs[1] = osc[0][0, PAD:].data_ptr(), osc[1][0, PAD:].data_ptr()
                 if form == "conv1":
                     d.act, d.act_slope = 3, 0.1
+                elif form == "conv2pl":          # the engine's default conv2: residual rebuilt from the plane set conv1 read, plane set out only
+                    rh, rq, rs = xr
+                    d.res, d.res_dtype, d.ldres, d.res_inv_slope = rh[PAD:].data_ptr(), 3, Cc, 10.0
+                    d.res_x4, d.res_xs, d.res_xs_stride = rq[1][PAD:].data_ptr(), rs[1][0, PAD:].data_ptr(), R * 4
                 else:
                     d.res, d.res_dtype, d.ldres, d.out32 = res.data_ptr(), 1, Cc, out.data_ptr()
                 d.reserved0 = (abl << 4) if abl >= 0 else (-1 - abl)
@@ -84,7 +88,7 @@ def main():
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / args.reps * 1e3
                 fl = 2.0 * M * Cc * Cc * k
-                by = M * Cc * (3.0625 * 2 + (8 if form == "conv2" else 0))
+                by = M * Cc * (3.0625 * 2 + (8 if form == "conv2" else (2.53 if form == "conv2pl" else 0)))
                 print("C=%d M=%d k=%2d %-5s %-24s %8.1f us  %6.0f TF/s alg  %5.2f TB/s contract" % (Cc, M, k, form, nm, us, fl / us / 1e6, by / us / 1e6), flush=True)
 
 
