@@ -498,6 +498,7 @@ def main():
     ap.add_argument("--mx-residual", default="planes", choices=["planes", "fp32"], help="ev_config.mx_residual (A/B: round 3's fp32 residual stream)")
     ap.add_argument("--mx-mrf", default="planes", choices=["planes", "fp32"], help="ev_config.mx_mrf (A/B: fp32 running MRF sum)")
     ap.add_argument("--decoder-ln", default="planes", choices=["planes", "fp32"], help="ev_config.decoder_ln_planes (A/B: fp32 LayerNorm output + planes pass)")
+    ap.add_argument("--token-splitk", default="on", choices=["on", "off"], help="ev_config.token_splitk (A/B: the token-rate long-K GEMMs in one pass)")
     ap.add_argument("--precision", default="mx", choices=["mx", "fast", "strict"],
                     help="frame-rate path: mx (default, the contract mode: waveform <= 1e-3 on every fixture) = fp32 activations, one fp16 MFMA + "
                          "two block-scaled fp4 MFMAs per product; fast = fp16 MFMA operands / fp16 activations (2.4e-3 on zero-mean audio); "
@@ -557,7 +558,7 @@ def main():
     def make_engine(precision, decoder_precision=None):
         e = EVEngine(device_id=local_rank, precision=precision, decoder_precision=decoder_precision,
                      vocoder_chunk_mb=args.chunk_mb, vocoder_streams=args.voc_streams, mx_residual=args.mx_residual,
-                     mx_mrf=args.mx_mrf, decoder_ln=args.decoder_ln)
+                     mx_mrf=args.mx_mrf, decoder_ln=args.decoder_ln, token_splitk=args.token_splitk == "on")
         e.load_blob_device(blob_t.data_ptr(), blob_t.numel(), keepalive=blob_t)
         return e
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVHIP_LIB", os.path.join(_HERE, "csrc", "libevhip.so"))
-EV_ABI_VERSION = 3
+EV_ABI_VERSION = 4
 EV_PREC_F16, EV_PREC_F32, EV_PREC_X3, EV_PREC_MX = 0, 1, 2, 3
 EV_FLAG_DEVICE_INPUTS, EV_FLAG_NO_VOCODER, EV_FLAG_WANT_INT16, EV_FLAG_FORCED_DURATIONS = 1, 2, 4, 8
 
@@ -27,7 +27,7 @@ class ev_config(C.Structure):
         ("sample_rate", C.c_int32), ("decoder_precision", C.c_int32), ("keep_stages", C.c_int32),
         ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("vocoder_streams", C.c_int32),
         ("vocoder_precision", C.c_int32), ("mx_residual", C.c_int32), ("decoder_attention", C.c_int32),
-        ("fused_pairs", C.c_int32), ("mx_mrf", C.c_int32), ("decoder_ln_planes", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("fused_pairs", C.c_int32), ("mx_mrf", C.c_int32), ("decoder_ln_planes", C.c_int32), ("token_splitk", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -66,7 +66,7 @@ class ev_conv_gemm_desc(C.Structure):
         ("out_scale", C.c_float), ("acc32", C.c_void_p), ("ldacc", C.c_int), ("post_lrelu", C.c_int),
         ("post_slope", C.c_float), ("out16", C.c_void_p), ("out32", C.c_void_p), ("ldo", C.c_int),
         ("out32_before_post", C.c_int), ("reserved0", C.c_int),
-        ("add16_a", C.c_void_p), ("add16_b", C.c_void_p), ("ldadd", C.c_int), ("reserved1", C.c_int),
+        ("add16_a", C.c_void_p), ("add16_b", C.c_void_p), ("ldadd", C.c_int), ("ksplit", C.c_int),
         ("W_mx", C.c_void_p), ("mx_scratch", C.c_void_p), ("mx_scratch_size", C.c_size_t),
         ("mx_x4", C.c_void_p * 2), ("mx_xs", C.c_void_p * 2), ("mx_xs_stride", C.c_uint), ("reserved2", C.c_int),
         ("mxo_h", C.c_void_p), ("mxo_q4", C.c_void_p * 2), ("mxo_qs", C.c_void_p * 2), ("mxo_qs_stride", C.c_uint),

@@ -72,6 +72,7 @@ struct ev_handle {
     char* sblob = nullptr; size_t sbytes = 0; ev_bert_config bcfg{}; bool style_loaded = false;
     // arena
     char* arena[3] = {nullptr, nullptr, nullptr}; size_t arena_bytes[3] = {0, 0, 0};   // [0] token-rate phase, [1] frame-rate phase + vocoder, [2] SimBERT
+    char* tok_ks = nullptr; size_t tok_ks_bytes = 0;          // split-K partial sums of the token-rate conv-FFN (tok_splitk); inside arena 0
     char* pinned = nullptr; size_t pinned_bytes = 0;
     // persistent outputs (host side)
     std::vector<int32_t> mel_lens; std::vector<int64_t> mel_offs;
@@ -313,6 +314,7 @@ int check_gemm(ev_handle* h, const ConvGemmParams& p) {
     if (!p.out16 && !p.out32 && !p.mxo_h) return fail(h, "gemm: no output");
     if (p.dtype == DT_MX && (p.K % 32 || !p.W)) return fail(h, "gemm: bad MX call");
     if (mx_check(p)) return fail(h, "gemm: inconsistent MX plane-set fields (dtype %d, N %d, K %d, taps %d)", p.dtype, p.N, p.K, p.taps);
+    if (splitk_check(p)) return fail(h, "gemm: inconsistent split-K call (ksplit %d, dtype %d, N %d, K %d)", p.ksplit, p.dtype, p.N, p.K);
     return 0;
 }
 // flop_scale: algorithmic / executed FLOPs (2/3 for a ConvTranspose1d run as a 3-tap conv: each output sample has two real taps)
@@ -380,6 +382,19 @@ struct RowCtx {     // one row layout (token rate or frame rate)
     int R; const uint8_t* valid; const int32_t* row_seq; const int32_t* seq_off; const int32_t* seq_len; int B; int max_len;
     double n_valid;
 };
+
+// Split-K of a token-rate GEMM (ev_config.token_splitk; ConvGemmParams::ksplit): a rule on the layer's shape only -- never on the row count -- so that an
+// utterance alone and inside a batch gets the same summation order.  It takes the conv-FFN's second conv (N = hidden, 144 (K-chunk, tap) steps: 4 ranges of 36);
+// N <= hidden keeps the partial-sum traffic (ksplit x M x N x 4 bytes, written and read once) small beside the operands.  Measured (bench.py --token-splitk,
+// one MI355X): B = 1, 64 / 256 phonemes 4.25 / 5.2 -> 3.95 / 4.85 ms; at 32 x 256 tokens the encoder pays +0.08 ms for the reduction launches.  The predictors'
+// k = 3 convs (36 steps) were tried with 3 ranges as well: another -0.07 ms at B = 1 for +0.14 ms at B = 32 -- left in one pass.
+void tok_splitk(ev_handle* h, ConvGemmParams& p) {
+    if (h->cfg.token_splitk != 0 || p.dtype != DT_F32S || p.N % 64 || p.N > h->cfg.hidden || p.add16_a) return;
+    const int nkc = p.K / 32, steps = nkc * p.taps;
+    const int S = (steps >= 144 && nkc % 4 == 0) ? 4 : 1;
+    if (S <= 1 || !h->tok_ks || (size_t)S * (size_t)p.M * (size_t)p.N * 4 > h->tok_ks_bytes) return;          // (the arena sizes the buffer for the rule's worst case)
+    p.ksplit = S; p.mx_scratch = h->tok_ks; p.mx_scratch_size = h->tok_ks_bytes;
+}
 
 // Encoder / decoder stack (reference modules/encoder.py:316-324, layer :154-200).  x (fp32 residual stream,
 // [R][C]) is updated in place; y receives after_norm(x) in `prec` dtype (and y32_tap in fp32 if given).
@@ -461,6 +476,7 @@ int run_stack(ev_handle* h, const char* pre, int layers, int prec, const RowCtx&
         p.dtype = prec; p.A = ffn.p; p.lda = F; p.W = wf2; p.bias = bf2; p.M = rc.R; p.N = C; p.K = F; p.taps = kf; p.center = (kf - 1) / 2;
         p.row_valid = rc.valid; p.res = x.p; p.res_dtype = DT_F32; p.ldres = C; p.out32 = (float*)x.p; p.ldo = C;
         if (prec == DT_F32 && tok_weights(h, lp + ".ffn2.w", p)) return -1;
+        if (!dmx && !strcmp(pre, "enc")) tok_splitk(h, p);
         if (ffn_mx) { p.dtype = DT_MX; p.W_mx = h->wt[lp + ".ffn2.wmx"].ptr; mx_in(p, fv, F); }
         if (gemm(h, ffn_mx ? (std::string(pre) + "_mx_gemm").c_str() : (kn + "_gemm").c_str(), p, rc.n_valid)) return -1;
         if (layer_taps) HIPCHK(h, hipMemcpyAsync((*layer_taps)[i].p, x.p, x.bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -984,8 +1000,8 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
         return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
     if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3 && cfg->vocoder_precision != EV_PREC_MX)
         return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16, EV_PREC_X3 or EV_PREC_MX");
-    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs | cfg->mx_mrf | cfg->decoder_ln_planes) & ~1)
-        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs / mx_mrf / decoder_ln_planes must be 0 or 1");
+    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs | cfg->mx_mrf | cfg->decoder_ln_planes | cfg->token_splitk) & ~1)
+        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs / mx_mrf / decoder_ln_planes / token_splitk must be 0 or 1");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));
@@ -1248,6 +1264,10 @@ int ev_synthesize(ev_handle* h, int B, const int64_t* ling, const int32_t* cu, c
         tb.t1b = ap.rows(Rt, C, 4); tb.t2b = ap.rows(Rt, C, 4); tb.t1c = ap.rows(Rt, C, 4); tb.t2c = ap.rows(Rt, C, 4);
         tb.pitch = ap.rows(Rt, 1, 4); tb.energy = ap.rows(Rt, 1, 4); tb.logd = ap.rows(Rt, 1, 4); tb.centre = ap.rows(Rt, 1, 4);
         if (keep) { tb.ltaps.resize(c.enc_layers); for (auto& b : tb.ltaps) b = ap.rows(Rt, C, 4); tb.tokemb_tap = ap.rows(Rt, C, 4); }
+        {          // split-K partial sums (tok_splitk): 4 ranges x hidden columns
+            const Buf kb = (c.token_splitk == 0 && c.token_rate_split != 0) ? ap.rows(Rt, 4 * C, 4) : Buf{};
+            h->tok_ks = kb.p; h->tok_ks_bytes = kb.p ? (size_t)Rt * 4 * C * 4 : 0;
+        }
         tok_arena_end = ap.off;
     }
     // token layout: B offsets / lengths / cu_seqlens through the pinned token region, per-row maps built on the device
@@ -1589,7 +1609,7 @@ int ev_op_conv_gemm(const ev_conv_gemm_desc* d, void* stream) {
     if (p.M % ROW_ALIGN || p.N % 32 || (p.K * es) % 64 || (p.taps - 1) * p.dil > 64) return -2;
     if (p.dtype == DT_F32S && (p.K % 32 || !p.W_lo)) return -2;
     if (p.dtype == DT_MX && (p.K % 32 || !p.W)) return -2;
-    if (mx_check(p)) return -2;
+    if (mx_check(p) || splitk_check(p)) return -2;
     if (!p.out16 && !p.out32 && !p.mxo_h) return -2;
     if (p.pro_lrelu && !(p.pro_slope >= 0.f && p.pro_slope <= 1.f)) return -2;
     launch_conv_gemm(p, (hipStream_t)stream);

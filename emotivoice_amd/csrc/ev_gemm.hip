@@ -1390,8 +1390,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
+    // split-K (ConvGemmParams::ksplit, launch_split): the grid is tiles x ksplit, the ranges of a tile are neighbours in the XCD-contiguous order (one L2
+    // holds the slab they share), block (tile, ks) walks the K-chunks [kc0, kc1) and writes its partial sums to the ks-th [M][N] slice behind out32
+    const int nks = p.ksplit > 1 ? p.ksplit : 1;
+    const int ks = bid % nks;
+    bid /= nks;
     const int m0 = (bid / nN) * BM, n0 = (bid % nN) * BN;
-    const int taps = p.taps, nkc = p.K >> 5, steps = nkc * taps;
+    const int taps = p.taps, nkc_all = p.K >> 5, kc0 = ks * (nkc_all / nks), nkc = nkc_all / nks, steps = nkc * taps;
     const long a_pitch = (long)p.lda * 4;
     const long w_tap_pitch = (long)p.K * 2, w_row_pitch = w_tap_pitch * taps;
 
@@ -1464,19 +1469,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
 #pragma unroll
     for (int a = 0; a < NT; ++a) woff[a] = swz(wc * TC + a * 16 + fr, fq);
 
-    EV_S_GLOAD_X(0)
-    EV_S_GLOAD_W(0, 0)
+    EV_S_GLOAD_X(kc0)
+    EV_S_GLOAD_W(kc0, 0)
     EV_S_SSTORE_X(0)
     EV_S_SSTORE_W(0)
     __syncthreads();
-    int kc = 0, tap = 0, wsel = 0;
+    int kc = 0, tap = 0, wsel = 0;          // kc counts from the range's first chunk (it also picks the slab buffer); kc0 + kc is the chunk
     for (int s = 0; s < steps; ++s) {
         int t1 = tap + 1, k1 = kc;
         if (t1 == taps) { t1 = 0; k1 = kc + 1; }
         const bool has_next = s + 1 < steps;
         const bool next_x = has_next && t1 == 0;
-        if (has_next) EV_S_GLOAD_W(k1, t1)
-        if (next_x) EV_S_GLOAD_X(k1)
+        if (has_next) EV_S_GLOAD_W(kc0 + k1, t1)
+        if (next_x) EV_S_GLOAD_X(kc0 + k1)
         {
             const int row0 = wt * TT + fr + tap * p.dil;
             const int xo = (kc & 1) * XBUF + row0 * 64 + ((fq ^ ((row0 >> 1) & 3)) << 4);
@@ -1520,11 +1525,94 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
     gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
 #else
     if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC);
-    else {
+    else if constexpr (EPI == EPI_O32) {
+        if (nks > 1) {          // (launch_split hands a split-K launch to this instantiation with a bare epilogue: out32 = the partial-sum slices, ldo = N)
+            ConvGemmParams pe = p;
+            pe.out32 = p.out32 + (size_t)ks * (size_t)p.M * (size_t)p.N;
+            EV_TRACE_EPI_DUMMY
+            gemm_epilogue_fast<MT, NT, EPI>(pe, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC EV_TRACE_EPI_ARGS);
+        } else {
+            EV_TRACE_EPI_DUMMY
+            gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC EV_TRACE_EPI_ARGS);
+        }
+    } else {
         EV_TRACE_EPI_DUMMY
         gemm_epilogue_fast<MT, NT, EPI>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * TT, n0 + wc * TC EV_TRACE_EPI_ARGS);
     }
 #endif
+}
+
+// second half of a split-K launch: out = epilogue( sum over the ksplit partial-sum slices, in range order ), the formula and the order of operations of
+// gemm_epilogue_lds.  One thread = 8 consecutive channels of a row.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams p, const float* __restrict__ ws) {
+    const int lpr = p.N >> 3;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long t = gid / lpr;
+    if (t >= p.M) return;
+    const int co = (int)(gid - t * lpr) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool valid = p.row_valid ? (p.row_valid[t >> p.valid_shift] != 0) : true;
+    if (valid) {
+        const size_t slice = (size_t)p.M * (size_t)p.N;
+        const float* wp = ws + (size_t)t * p.N + co;
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4*>(wp + s * slice), a1 = *reinterpret_cast<const float4*>(wp + s * slice + 4);
+            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+        }
+        if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act, p.act_slope);
+        }
+        if (p.seq_bias) {
+            const float* sb = p.seq_bias + (long)p.row_seq[t] * p.ld_seq_bias + co;
+            const float4 s0 = *reinterpret_cast<const float4*>(sb), s1 = *reinterpret_cast<const float4*>(sb + 4);
+            v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+        }
+        if (p.res) {
+            if (p.res_dtype == DT_F16) {
+                const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p.res) + t * p.ldres + co);
+                const __half2* h = reinterpret_cast<const __half2*>(&r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); v[2 * e] += f.x; v[2 * e + 1] += f.y; }
+            } else {
+                const float* rp = reinterpret_cast<const float*>(p.res) + t * p.ldres + co;
+                const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        if (p.acc32) {
+            const float* rp = p.acc32 + t * p.ldacc + co;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+    }
+    if (p.out32 && p.out32_before_post) {
+        float* op = p.out32 + t * p.ldo + co;
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (p.post_lrelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.post_slope;
+    }
+    if (p.out32 && !p.out32_before_post) {
+        float* op = p.out32 + t * p.ldo + co;
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (p.out16) {
+        uint4 o;
+        __half2* h = reinterpret_cast<__half2*>(&o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.out16) + t * p.ldo + co) = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1568,8 +1656,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const ConvGemmPara
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
+    // split-K (ConvGemmParams::ksplit, launch_split): the grid is tiles x ksplit, the ranges of a tile are neighbours in the XCD-contiguous order (one L2
+    // holds the slab they share), block (tile, ks) walks the K-chunks [kc0, kc1) and writes its partial sums to the ks-th [M][N] slice behind out32
+    const int nks = p.ksplit > 1 ? p.ksplit : 1;
+    const int ks = bid % nks;
+    bid /= nks;
     const int m0 = (bid / nN) * BM, n0 = (bid % nN) * BN;
-    const int taps = p.taps, nkc = p.K >> 5, steps = nkc * taps;
+    const int taps = p.taps, nkc_all = p.K >> 5, kc0 = ks * (nkc_all / nks), nkc = nkc_all / nks, steps = nkc * taps;
     const long a_pitch = (long)p.lda * 4;
     const long w_tap_pitch = (long)p.K * 2, w_row_pitch = w_tap_pitch * taps;
 
@@ -1765,7 +1858,7 @@ static void launch_split_bn(const ConvGemmParams& p, hipStream_t s) {
     const size_t epi = 4 * (size_t)(32 * ((BN / 2) * 4 + 16));
     if (epi > lds) lds = epi;
     static_assert(4 * (size_t)(BM + MAX_SPAN) * 64 + 4 * (size_t)BN * 64 <= 65536, "within the default dynamic-LDS limit: no per-device opt-in needed");
-    const int grid = (p.M / BM) * (p.N / BN);
+    const int grid = (p.M / BM) * (p.N / BN) * (p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((conv_gemm_split_kernel<BM, BN, EPI>), dim3(grid), dim3(256), lds, s, p);
 }
 template <int EPI>
@@ -1787,6 +1880,18 @@ static void launch_split(const ConvGemmParams& p, hipStream_t s) {
     // few tiles (the token-rate GEMMs: 33 x 3..12 tiles of 256 x 128 at 32 x 256 tokens) cannot fill 256 CUs with one 8-wave block
     // each: the first-generation kernel's 128 x 64 tiles at two 4-wave blocks per CU give 4x the blocks (measured: encoder GEMMs
     // 1.40 ms vs 1.81 ms, predictors 0.31 vs 0.54 ms)
+    if (p.ksplit > 1) {
+        // split-K (checked by splitk_check): every (tile, K range) is a block of the 128 x 64-tile kernel with a bare fp32 epilogue into the scratch slices,
+        // then the reduction applies the call's own epilogue.  Whatever M is: the summation order must not depend on the batch.
+        ConvGemmParams q = p;
+        q.bias = nullptr; q.act = ACT_NONE; q.row_valid = nullptr; q.row_seq = nullptr; q.seq_bias = nullptr; q.res = nullptr; q.acc32 = nullptr;
+        q.out_scale = 1.0f; q.post_lrelu = 0; q.out16 = nullptr; q.out32_before_post = 0; q.add16_a = nullptr; q.add16_b = nullptr;
+        q.out32 = reinterpret_cast<float*>(p.mx_scratch); q.ldo = p.N;
+        launch_split_bn<64, EPI_O32>(q, s);
+        const long threads = (long)p.M * (p.N / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, reinterpret_cast<const float*>(p.mx_scratch));
+        return;
+    }
     const long tiles_x3 = (long)(p.M / 256) * (p.N % 128 == 0 ? p.N / 128 : (p.N % 64 == 0 ? p.N / 64 : p.N / 32));
     if (old_kernel || (tiles_x3 < 512 && p.N % 64 == 0)) {      // (same epilogue variant as the second-generation kernel would take)
         if (plain && !p.acc32 && !p.res && !rare_act) return launch_split_epi<EPI_O32>(p, s);
@@ -2520,6 +2625,13 @@ void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s) {
 int mx_launch_kind(const ConvGemmParams& p) {
     if (p.dtype != DT_MX) return 0;
     return conv64_mx_eligible(p) ? 2 : (mx_eligible(p) ? 1 : 0);
+}
+
+int splitk_check(const ConvGemmParams& p) {
+    if (p.ksplit <= 1) return 0;
+    if (p.dtype != DT_F32S || p.ksplit > 16 || p.N % 64 || p.K % 32 || (p.K / 32) % p.ksplit || p.M % 128 || p.add16_a || (!p.out32 && !p.out16)) return -1;
+    if (!p.mx_scratch || ((uintptr_t)p.mx_scratch & 15) || p.mx_scratch_size < (size_t)p.ksplit * (size_t)p.M * (size_t)p.N * 4) return -1;
+    return 0;
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {

@@ -47,7 +47,11 @@ struct ConvGemmParams {
     int reserved0;                               // (was: ablation switches used while tuning)
     const void* add16_a; const void* add16_b; int ldadd;   // two fp16 tensors added after scaling (the MRF sum of three ResBlocks
                                                  // with the first two branches kept in fp16: half the traffic of acc32), or null
-    int reserved1;
+    int ksplit;                                  // DT_F32S, N % 64 == 0, no add16: > 1 = split-K.  The K / 32 chunks are cut into `ksplit` equal ranges (K / 32 must be a
+                                                 // multiple), each (tile, range) is a block of the 128 x 64-tile kernel writing fp32 partial sums to mx_scratch
+                                                 // (>= ksplit * M * N * 4 bytes), and a second kernel adds them in range order and applies the epilogue.  Shortens the
+                                                 // sequential step chain of the token-rate GEMMs (few tiles, K * taps up to 4608).  The summation order differs from
+                                                 // ksplit <= 1, so a caller that promises batch invariance picks it by layer shape, never by M.
     // DT_MX only.  W_mx: the weight's fp4 planes (emotivoice_amd/mxfp4.py: pack_weight_planes), null -> the call runs as DT_F32S.
     // Activations, either (a) A = fp32 [M][K] + mx_scratch (>= mx_scratch_bytes(M, K) bytes): the launcher first runs mx_planes_kernel
     // (leaky-relu of pro_lrelu, then the planes) into the scratch, or (b) a plane set written by the producer's epilogue (mxo below):
@@ -77,6 +81,8 @@ struct ConvGemmParams {
 size_t mx_scratch_bytes(int M, int K);
 // 0 if the plane-set fields of a call are consistent with its dtype, shape and epilogue (launch_conv_gemm would run it)
 int mx_check(const ConvGemmParams& p);
+// 0 if ConvGemmParams::ksplit is consistent with the rest of the call (<= 1, or a DT_F32S call whose shape and scratch allow the split)
+int splitk_check(const ConvGemmParams& p);
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
 // which kernel launch_conv_gemm runs a DT_MX call on: 0 = the split-precision fallback (three fp16 MFMAs per product), 1 = conv_gemm_mx_kernel,
 // 2 = conv_c64_mx_kernel (profiling records name the launch by this, not by what the caller hoped for)

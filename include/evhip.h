@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 3      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info;
-                                 3: ev_config.mx_mrf / decoder_ln_planes, partial plane sets in ev_conv_gemm_desc (acc_h ..., mxo_partial) */
+#define EV_ABI_VERSION 4      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info;
+                                 3: ev_config.mx_mrf / decoder_ln_planes, partial plane sets in ev_conv_gemm_desc (acc_h ..., mxo_partial);
+                                 4: ev_config.token_splitk, ev_conv_gemm_desc.ksplit (same struct sizes) */
 
 typedef struct ev_handle ev_handle;
 
@@ -94,7 +95,12 @@ typedef struct ev_config {
                                    transfer, re-quantised once per ResBlock; emulated cost 5e-6 of waveform error); 1 = an fp32 running sum */
     int32_t decoder_ln_planes;  /* EV_PREC_MX decoder: 0 (default) = the LayerNorms in front of the QKV projection and the conv-FFN write the plane sets those
                                    layers read (no fp32 copy, no separate quantisation pass; the same bits); 1 = fp32 output + a planes pass */
-    int32_t reserved[2];
+    int32_t token_splitk;       /* token-rate stack with split hi/lo GEMMs: 0 (default) = the phoneme encoder's second conv-FFN conv (N = hidden, K x taps = 4608:
+                                   144 sequential (K-chunk, tap) steps per tile) runs split-K -- 4 ranges, partial sums reduced in range order by a second
+                                   kernel -- because that chain is what a single utterance waits for (B = 1, 64 phonemes: 4.25 -> 3.95 ms; +0.08 ms per
+                                   32 x 256-token batch).  Chosen by layer shape only: an utterance alone and in a batch gets the same bits.
+                                   1 = every GEMM in one pass (the summation order of rounds 1-3) */
+    int32_t reserved[1];
 } ev_config;
 
 /* Precision of the frame-rate path.  F16: fp16 MFMA operands (what BASELINE.json's bf16 / fp16 configs name).

@@ -40,7 +40,11 @@ typedef struct ev_conv_gemm_desc {
     int out32_before_post;
     int reserved0;
     const void* add16_a; const void* add16_b; int ldadd;   /* two fp16 [M][N] tensors added after scaling (both or neither), or NULL */
-    int reserved1;
+    int ksplit;                                  // DT_F32S, N % 64 == 0, no add16: > 1 = split-K.  The K / 32 chunks are cut into `ksplit` equal ranges (K / 32 must be a
+                                                 // multiple), each (tile, range) is a block of the 128 x 64-tile kernel writing fp32 partial sums to mx_scratch
+                                                 // (>= ksplit * M * N * 4 bytes), and a second kernel adds them in range order and applies the epilogue.  Shortens the
+                                                 // sequential step chain of the token-rate GEMMs (few tiles, K * taps up to 4608).  The summation order differs from
+                                                 // ksplit <= 1, so a caller that promises batch invariance picks it by layer shape, never by M.
     const void* W_mx;          /* dtype 3: emotivoice_amd/mxfp4.py pack_weight_planes(W) on the device (NULL: the call runs as dtype 2) */
     void* mx_scratch; size_t mx_scratch_size;   /* dtype 3 with fp32 A: device scratch, >= ev_op_mx_scratch_bytes(M, K) */
     const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int reserved2;   /* dtype 3 with a plane-set input: A = its fp16 hi

@@ -49,7 +49,7 @@ def test_struct_layouts_match_the_c_headers(tmp_path):
 def test_abi_info_reports_what_the_binding_expects():
     """ev_abi_info is what _ffi.lib() checks at load time: a stale libevhip.so or a stale binding must fail there."""
     sizes = (C.c_size_t * 4)()
-    assert _ffi.lib().ev_abi_info(sizes) == _ffi.EV_ABI_VERSION == 3
+    assert _ffi.lib().ev_abi_info(sizes) == _ffi.EV_ABI_VERSION == 4
     assert tuple(sizes) == (C.sizeof(_ffi.ev_config), C.sizeof(_ffi.ev_result), C.sizeof(_ffi.ev_conv_gemm_desc), C.sizeof(_ffi.ev_res_pair_desc))
     hdr = open(os.path.join(ROOT, "include", "evhip.h")).read()
     assert re.search(r"#define EV_ABI_VERSION\s+%d\b" % _ffi.EV_ABI_VERSION, hdr)
@@ -59,12 +59,12 @@ def test_engine_switches_are_config_fields_not_environment_variables():
     """Round 3's EV_MX_RESPL / EV_ATTN_F32 / EV_NO_FUSED_PAIR became ev_config fields; the product library calls getenv nowhere."""
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
-    assert (cfg.mx_residual, cfg.decoder_attention, cfg.fused_pairs, cfg.mx_mrf, cfg.decoder_ln_planes) == (0, 0, 0, 0, 0)
+    assert (cfg.mx_residual, cfg.decoder_attention, cfg.fused_pairs, cfg.mx_mrf, cfg.decoder_ln_planes, cfg.token_splitk) == (0, 0, 0, 0, 0, 0)
     from emotivoice_amd.engine import make_ev_config
     from emotivoice_amd.config import EVShapes
     c2 = make_ev_config(EVShapes(), "mx", vocoder_precision="mx", mx_residual="fp32", decoder_attention="f32", fused_pairs=False, mx_mrf="fp32",
-                        decoder_ln="fp32")
-    assert (c2.mx_residual, c2.decoder_attention, c2.fused_pairs, c2.mx_mrf, c2.decoder_ln_planes) == (1, 1, 1, 1, 1)
+                        decoder_ln="fp32", token_splitk=False)
+    assert (c2.mx_residual, c2.decoder_attention, c2.fused_pairs, c2.mx_mrf, c2.decoder_ln_planes, c2.token_splitk) == (1, 1, 1, 1, 1, 1)
     with pytest.raises(KeyError):
         make_ev_config(EVShapes(), mx_residual="bf16")
     out = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True).stdout
@@ -113,7 +113,8 @@ def test_ev_create_rejects_shapes_the_kernels_do_not_build():
                        (dict(var_embed_kernel=13), "conv kernels"), (dict(rb_kernels=[3, 7, 15]), "ResBlock kernel"),
                        (dict(vocoder_precision=1), "vocoder_precision"), (dict(decoder_precision=7), "decoder_precision"),
                        (dict(n_rb=5), "generator layout"), (dict(abi_version=99), "abi_version"), (dict(abi_version=1), "abi_version"),
-                       (dict(mx_residual=2), "mx_residual"), (dict(mx_mrf=3), "mx_mrf"), (dict(abi_version=2), "abi_version")):
+                       (dict(mx_residual=2), "mx_residual"), (dict(mx_mrf=3), "mx_mrf"), (dict(abi_version=2), "abi_version"), (dict(abi_version=3), "abi_version"),
+                       (dict(token_splitk=2), "token_splitk")):
         rc, msg = create(**kw)
         assert rc != 0 and needle in msg, (kw, msg)
 

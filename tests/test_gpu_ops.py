@@ -471,6 +471,84 @@ def test_split_precision_gemm_matches_fp32(lib, M, K, N, taps):
     assert errs[2] < 3e-6, errs          # within a small factor of fp32 rounding
 
 
+@pytest.mark.parametrize("M,K,N,taps,S,form", [(256, 1536, 384, 3, 4, "res"), (768, 384, 384, 3, 3, "relu"), (1024, 384, 384, 3, 3, "plain"), (512, 1536, 384, 3, 2, "full"),
+                                               (256, 384, 64, 1, 12, "plain")])
+def test_split_k_token_rate_gemm(lib, M, K, N, taps, S, form):
+    """ev_conv_gemm_desc.ksplit: the K-chunks of a split-precision (hi / lo weights) GEMM cut into S ranges, one block of the 128 x 64-tile kernel per (tile, range)
+    writing fp32 partial sums, a second kernel reducing them in range order and applying the epilogue (the token-rate conv-FFN / predictor convs: ev_config.
+    token_splitk).  Held to the same bound against fp64 as the one-pass kernel, equal to it to fp32 rounding, bit-identical between two launches and to the
+    same rows computed inside a larger M (batch invariance), invalid rows exact zeros; inconsistent calls are refused."""
+    from emotivoice_amd import _ffi
+    torch.manual_seed(M + K + N + S)
+    Mbig = M + 512
+    full, xbig = _padded(Mbig, K, torch.float32)
+    full[:PAD] = 0
+    full[PAD + M:PAD + M + 128] = 0                 # a gap behind the first M rows: they see the same neighbourhood alone and inside the larger launch
+    full[PAD + Mbig:] = 0
+    x = xbig[:M]
+    w = torch.randn(N, K, taps, device="cuda") / math.sqrt(K * taps)
+    bias = torch.randn(N, device="cuda")
+    wg = w.permute(0, 2, 1).contiguous()
+    hi = wg.half()
+    lo = ((wg - hi.float()) * 2048.0).half()
+    res = torch.randn(Mbig, N, device="cuda")
+    acc = torch.randn(Mbig, N, device="cuda")
+    valid = torch.ones(Mbig // 8, dtype=torch.uint8, device="cuda")
+    valid[1] = 0
+    valid[M // 8:(M + 128) // 8] = 0
+    ws = torch.zeros(S * Mbig * N + 4, dtype=torch.float32, device="cuda")
+
+    def run(rows, ksplit, scratch=True):
+        d = _ffi.ev_conv_gemm_desc()
+        d.dtype, d.A, d.lda, d.W, d.W_lo = 2, xbig.data_ptr(), K, hi.data_ptr(), lo.data_ptr()
+        d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), rows, N, K, taps, 1, (taps - 1) // 2, 1.0
+        d.row_valid, d.valid_shift = valid.data_ptr(), 3
+        if form == "relu":
+            d.act = 1
+        if form in ("res", "full"):
+            d.res, d.res_dtype, d.ldres = res.data_ptr(), 1, N
+        if form == "full":
+            d.act, d.out_scale, d.acc32, d.ldacc, d.post_lrelu, d.post_slope = 2, 0.5, acc.data_ptr(), N, 1, 0.2
+        out = torch.full((rows, N), 7.0, device="cuda")
+        d.out32, d.ldo = out.data_ptr(), N
+        d.ksplit = ksplit
+        if ksplit > 1 and scratch:
+            d.mx_scratch, d.mx_scratch_size = ws.data_ptr(), S * rows * N * 4
+        torch.cuda.synchronize()
+        rc = lib.ev_op_conv_gemm(C.byref(d), None)
+        torch.cuda.synchronize()
+        return rc, out
+
+    rc, one = run(M, 0)
+    assert rc == 0
+    rc, spl = run(M, S)
+    assert rc == 0
+    rc, spl2 = run(M, S)
+    assert rc == 0 and torch.equal(spl, spl2)
+    rc, big = run(Mbig, S)
+    assert rc == 0 and torch.equal(big[:M], spl)                 # the same rows inside a larger launch: same bits
+    ref = F.conv1d(x.double().cpu().t().unsqueeze(0), w.double().cpu(), bias.double().cpu(), padding=(taps - 1) // 2).squeeze(0).t()
+    if form == "relu":
+        ref = ref.clamp(min=0)
+    if form == "full":
+        ref = 0.5 * ref * (1.0 + torch.erf(ref / math.sqrt(2.0)))
+    if form in ("res", "full"):
+        ref = ref + res[:M].double().cpu()
+    if form == "full":
+        ref = ref * 0.5 + acc[:M].double().cpu()
+        ref = torch.where(ref > 0, ref, ref * 0.2)
+    vrow = valid[:M // 8].bool().repeat_interleave(8).cpu()
+    ref[~vrow] = 0
+    assert float(spl[~vrow.cuda()].abs().max()) == 0.0
+    e1, es = _rel(one.cpu().double(), ref), _rel(spl.cpu().double(), ref)
+    assert e1 < 3e-6 and es < 3e-6, (e1, es)
+    assert _rel(spl.cpu().double(), one.cpu().double()) < 1e-6
+    # refused: no scratch, a range count that does not divide the K-chunks, a dtype without the split kernel
+    assert run(M, S, scratch=False)[0] == -2
+    if (K // 32) % 5:
+        assert run(M, 5)[0] == -2
+
+
 @pytest.mark.parametrize("C_,k,dil", [(32, 11, 5), (32, 3, 1), (64, 7, 3), (128, 11, 5), (96, 7, 1)])
 def test_split_precision_generator_convs(lib, C_, k, dil):
     """The split-precision (EV_PREC_X3) form of the HiFi-GAN ResBlock convs (models/hifigan/models.py:50-57,121-126): fp32

@@ -90,7 +90,9 @@ def _engine(wmode, prec="fast", keep=True):
     key = ("eng", wmode, prec, keep)
     if key not in _CACHE:
         dp, vp = MODES[prec]
-        eng = EVEngine(decoder_precision=dp, vocoder_precision=vp, keep_stages=keep, mx_residual="fp32" if prec == "mx32" else "planes")
+        # "mx32": round 3's flow -- fp32 residual stream, and (round 4) the token-rate conv-FFN in one pass instead of split-K: the opt-outs stay under test
+        eng = EVEngine(decoder_precision=dp, vocoder_precision=vp, keep_stages=keep, mx_residual="fp32" if prec == "mx32" else "planes",
+                       token_splitk=prec != "mx32")
         _, blob, man = _weights(wmode)
         eng.load_blob(blob, man)
         _CACHE[key] = eng
