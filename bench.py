@@ -39,11 +39,12 @@ VOC_STAGE2_K3_RB_FLOP_PER_FRAME = 18.874e6         # stage-2 k = 3 ResBlock (C =
 VOC_BYTES_PER_FRAME = 2.026e6                      # layer-wise fp16 contract
 # the mx mode's own layer-wise contract: plane sets of 3.0625 B per element between the >= 64-channel layers (conv1 of a pair:
 # planes in / planes out; conv2: planes + fp32 residual in, fp32 + planes out), fp32 running MRF sums, the fused C = 32 pairs at 8 B per element
-def mx_contract_bytes_per_frame(residual_from_planes=True):
+def mx_contract_bytes_per_frame(residual_from_planes=True, mrf_partial_planes=True):
     """Layer-wise HBM bytes per mel frame of the generator's OWN data flow in the mx mode (not SURVEY 8(d)'s numerator: that is VOC_BYTES_PER_FRAME,
     reported as hbm_algorithmic_*).  P = 3.0625 B per element of a plane set (fp16 hi 2 + two fp4 code planes 0.5 + 0.5 + two E8M0 scales 1/32 each);
     a residual rebuilt from planes reads hi + remainder codes + their scales = 2.53125 B; stages 0-2: every conv planes in / planes out, conv2
-    + residual, the last conv of a ResBlock + the fp32 running MRF sum; stage 3: fused pairs, fp32 in / out (8 B per element and pair)."""
+    + residual, the last conv of a ResBlock + the running MRF sum (fp32; stages 0-1 since round 4: a partial plane set of R bytes per element, the stage
+    output only as the next up-conv's planes); stage 3: fused pairs, fp32 in / out (8 B per element and pair)."""
     P, R = 3.0625, 2.53125
     E, Ein = [2048, 8192, 8192, 8192], [512, 2048, 8192, 8192]       # elements per mel frame of a stage's tensors / of its up-conv's input
     b = 80 * 4 + 512 * 4 + 512 * 4 + 512 * P                         # conv_pre (fp32 in / out), its output's planes
@@ -62,13 +63,17 @@ def mx_contract_bytes_per_frame(residual_from_planes=True):
                 b += 2 * e * P + e * P + res                              # conv1 in / out, conv2 xt in + residual
                 if d < 2:
                     b += e * P + (0 if residual_from_planes else 4 * e)
+                elif mrf_partial_planes and residual_from_planes and s < 2:
+                    # stages with >= 128 channels: the running sum as a partial plane set (hi plane + remainder codes + their scales = R bytes per element),
+                    # the third ResBlock writes the next up-conv's full plane set directly
+                    b += (e * R if j else 0) + (e * P if j == 2 else e * R)
                 else:
                     b += (4 * e if j else 0) + 4 * e + (e * P if j == 2 else 0)     # running MRF sum in / out (or the stage output + its planes)
     return b + E[3] * 4 + 256 * 4                                    # conv_post
 
 
-# per-mode layer-wise contracts of the modes' own data flows (fp16: SURVEY 8(d); split precision: fp32 tensors; mx: 3.336 MB with the residual
-# rebuilt from planes and the fused k = 3 pairs of stage 2 -- the default since round 4 --, 4.310 MB with a separate fp32 residual tensor)
+# per-mode layer-wise contracts of the modes' own data flows (fp16: SURVEY 8(d); split precision: fp32 tensors; mx: the residual rebuilt
+# from planes, the fused k = 3 pairs of stage 2 and the MRF sums of stages 0-1 as partial plane sets -- the defaults since round 4; 4.310 MB with round 3's flow)
 VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": mx_contract_bytes_per_frame(True)}
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
