@@ -1656,13 +1656,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const ConvGemmPara
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    // split-K (ConvGemmParams::ksplit, launch_split): the grid is tiles x ksplit, the ranges of a tile are neighbours in the XCD-contiguous order (one L2
-    // holds the slab they share), block (tile, ks) walks the K-chunks [kc0, kc1) and writes its partial sums to the ks-th [M][N] slice behind out32
-    const int nks = p.ksplit > 1 ? p.ksplit : 1;
-    const int ks = bid % nks;
-    bid /= nks;
     const int m0 = (bid / nN) * BM, n0 = (bid % nN) * BN;
-    const int taps = p.taps, nkc_all = p.K >> 5, kc0 = ks * (nkc_all / nks), nkc = nkc_all / nks, steps = nkc * taps;
+    const int taps = p.taps, nkc = p.K >> 5, steps = nkc * taps;
     const long a_pitch = (long)p.lda * 4;
     const long w_tap_pitch = (long)p.K * 2, w_row_pitch = w_tap_pitch * taps;
 
@@ -2542,6 +2537,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
 }
 
 #include "ev_gemm_mx.h"
+#include "ev_gemm_mx64.h"
 #include "ev_pair_mx.h"
 
 #include "ev_conv64_mx.h"
@@ -2566,6 +2562,7 @@ int init_device_kernels(int device) {
     if (x3_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (phased_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
+    if (mx64_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (pair_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (conv64_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (pair64_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
@@ -2624,7 +2621,7 @@ void launch_resblock_pair_c64(const ResPairParams& p, hipStream_t s) {
 
 int mx_launch_kind(const ConvGemmParams& p) {
     if (p.dtype != DT_MX) return 0;
-    return conv64_mx_eligible(p) ? 2 : (mx_eligible(p) ? 1 : 0);
+    return (mx64_eligible(p) || conv64_mx_eligible(p)) ? 2 : (mx_eligible(p) ? 1 : 0);
 }
 
 int splitk_check(const ConvGemmParams& p) {
@@ -2640,7 +2637,8 @@ void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) {
     if (p.dtype == DT_F16) launch_dt<_Float16>(p, s);
     else if (p.dtype == DT_F32S) launch_split(p, s);
     else if (p.dtype == DT_MX) {
-        if (conv64_mx_eligible(p)) launch_conv64_mx(p, s);
+        if (mx64_eligible(p)) launch_mx64(p, s);
+        else if (conv64_mx_eligible(p)) launch_conv64_mx(p, s);
         else if (mx_eligible(p)) launch_mx(p, s);
         else { ConvGemmParams q = p; q.dtype = DT_F32S; launch_split(q, s); }      // same operands, three fp16 MFMAs per product
     } else launch_dt<float>(p, s);

@@ -433,9 +433,10 @@ static bool mx_eligible(const ConvGemmParams& p) {
 }
 // 0 = this DT_MX call can run (as the MX kernel, or -- fp32 input, no plane output -- as the split-precision fallback)
 static bool conv64_mx_eligible(const ConvGemmParams& p);
+static bool mx64_eligible(const ConvGemmParams& p);
 int mx_check(const ConvGemmParams& p) {
     if (p.dtype != DT_MX) return p.mxo_h || mx_planes_in(p) || (p.res && p.res_dtype == DT_MX) || p.acc_h || p.mxo_partial ? -1 : 0;       // plane sets exist only between DT_MX launches
-    if (mx_eligible(p) || conv64_mx_eligible(p)) return 0;
+    if (mx_eligible(p) || mx64_eligible(p) || conv64_mx_eligible(p)) return 0;
     return (p.mxo_h || mx_planes_in(p) || !p.W_lo || (p.res && p.res_dtype == DT_MX) || p.acc_h || p.mxo_partial) ? -1 : 0;
 }
 MxScratchPlanes mx_scratch_planes(void* scratch, int M, int K) {

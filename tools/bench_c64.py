@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=4227072)
     ap.add_argument("--ks", default="3,7,11")
+    ap.add_argument("--ab", action="store_true", help="only the A/B of the two kernels that can run a k = 7 / 11 launch: the streamed conv_gemm_mx64_kernel (default) against the persistent conv_c64_mx_kernel (reserved0 bit 3)")
     args = ap.parse_args()
     lib = _ffi.lib()
     M, Cc = args.rows // 256 * 256, 64
@@ -34,14 +35,15 @@ def main():
     res = torch.randn(M, Cc, device="cuda", generator=g)
     out = torch.empty(M, Cc, device="cuda")
     bias = torch.zeros(Cc, device="cuda")
+    names_ab = {0: "streamed (mx64)", -8: "persistent (c64)", -1: "streamed (again)", -9: "persistent (again)"}
     names = {0: "full", 1: "no plane stores", 2: "no fp32 stores", 4: "no slab requests", 8: "no MFMAs", 16: "no LDS slab writes", 32: "no plane quantisation",
              3: "no stores at all", 63: "loop skeleton only"}
     for k in [int(x) for x in args.ks.split(",")]:
         wg = (np.random.default_rng(k).standard_normal((Cc, k, Cc)) / np.sqrt(Cc * k)).astype(np.float32)
         d_hi = torch.from_numpy(wg.astype(np.float16)).cuda()
         d_mx = torch.from_numpy(mxfp4.pack_c64_weight_planes(wg)).cuda()
-        for form in ("conv1", "conv2"):
-            for abl, nm in names.items():
+        for form in ("conv1", "conv2", "conv2pl") if args.ab else ("conv1", "conv2"):
+            for abl, nm in (names_ab if args.ab else names).items():
                 d = _ffi.ev_conv_gemm_desc()
                 d.dtype, d.A, d.lda, d.W, d.W_lo, d.W_mx = 3, h[PAD:].data_ptr(), Cc, d_hi.data_ptr(), d_hi.data_ptr(), d_mx.data_ptr()
                 d.mx_x4[0], d.mx_x4[1], d.mx_xs[0], d.mx_xs[1], d.mx_xs_stride = q[0][PAD:].data_ptr(), q[1][PAD:].data_ptr(), s[0][PAD:].data_ptr(), s[1][PAD:].data_ptr(), R * 4
@@ -50,9 +52,12 @@ def main():
                 d.mxo_q4[0], d.mxo_q4[1], d.mxo_qs[0], d.mxo_qs[1] = oq[0][PAD:].data_ptr(), oq[1][PAD:].data_ptr(), osc[0][PAD:].data_ptr(), osc[1][PAD:].data_ptr()
                 if form == "conv1":
                     d.act, d.act_slope = 3, 0.1
+                elif form == "conv2pl":          # the engine's conv2: residual from the plane set conv1 read, plane set out
+                    d.res, d.res_dtype, d.ldres, d.res_inv_slope, d.out_scale = h[PAD:].data_ptr(), 3, Cc, 10.0, 1.0
+                    d.res_x4, d.res_xs, d.res_xs_stride = q[1][PAD:].data_ptr(), s[1][PAD:].data_ptr(), R * 4
                 else:
                     d.res, d.res_dtype, d.ldres, d.out32 = res.data_ptr(), 1, Cc, out.data_ptr()
-                d.reserved0 = abl << 4
+                d.reserved0 = (abl << 4) if abl >= 0 and not args.ab else (8 if abl in (-8, -9) else 0)
                 for _ in range(2):
                     assert lib.ev_op_conv_gemm(C.byref(d), None) == 0
                 torch.cuda.synchronize()
