@@ -257,16 +257,22 @@ static hipError_t mx64_attr_taps() {
 #undef EV_MX64_ATTR
     return e;
 }
-static hipError_t mx64_set_attributes() { return mx64_attr_taps<11>(); }
-// DT_MX call with N = K = 64, k = 11, plane sets in (the generator's stage-2 ResBlock convs): the streamed kernel.  A function of the layer's shape and of the
+static hipError_t mx64_set_attributes() {
+    hipError_t e = hipSuccess, r;
+    r = mx64_attr_taps<7>(); if (r != hipSuccess) e = r;
+    r = mx64_attr_taps<11>(); if (r != hipSuccess) e = r;
+    return e;
+}
+// DT_MX call with N = K = 64, k = 7 / 11, plane sets in (the generator's stage-2 ResBlock convs): the streamed kernel.  A function of the layer's shape and of the
 // epilogue form only; reserved0 bit 3 = in-process A/B switch of the op tests / tools (the persistent conv_c64_mx_kernel).
-// Measured at the stage-2 size of configs[1] (tools/bench_c64.py --ab, 4.2 M rows): k = 11 conv1 727 against 772 us, conv2 (residual from planes) 720 against 764;
-// k = 7 (12 steps per tile, the kernel also compiles for it) 594-606 against 593-604: a tile's fixed cost -- opening round trip, epilogue, ~10 of its 18-22 us -- is
-// what both kernels pay, so k = 7 stays on the persistent kernel.
+// Measured at the stage-2 size of configs[1] (4.2 M rows).  Isolated (tools/bench_c64.py --ab): k = 11 conv1 727 against 772 us, conv2 (residual from planes) 720
+// against 764; k = 7 (12 steps per tile) 594-606 against 593-604.  In the forward (bench.py per-launch table): k = 11 conv1 / conv2 / conv2 + fp32 MRF sum
+// 0.68-0.70 / 0.73-0.77 / 0.85 ms (persistent: 0.75-0.80 / 0.85-0.88 / 1.06), k = 7 0.53 / 0.62 / 0.77 (0.50-0.55 / 0.63-0.65 / 0.84): the family 9.05 -> 8.37 ms.
+// What neither kernel escapes is a tile's fixed cost -- opening round trip, plane-set epilogue: ~10 of the 18-22 us a 256 x 64 tile lives.
 static bool mx64_eligible(const ConvGemmParams& p) {
-    return p.W_mx && p.N == 64 && p.K == 64 && p.lda == 64 && p.taps == 11 && p.M % PH_BM == 0 && (p.taps - 1) * p.dil <= MAX_SPAN &&
+    return p.W_mx && p.N == 64 && p.K == 64 && p.lda == 64 && (p.taps == 11 || p.taps == 7) && p.M % PH_BM == 0 && (p.taps - 1) * p.dil <= MAX_SPAN &&
            p.center * 2 == p.taps - 1 && p.mx_x4[0] && p.mx_x4[1] && p.mx_xs[0] && p.mx_xs[1] && !p.pro_lrelu && !(p.reserved0 & 8) && mx_epi_variant(p) >= 0;
 }
 static void launch_mx64(const ConvGemmParams& p, hipStream_t s) {
-    launch_mx64_taps<11>(p, mx_epi_variant(p), s);
+    if (p.taps == 7) launch_mx64_taps<7>(p, mx_epi_variant(p), s); else launch_mx64_taps<11>(p, mx_epi_variant(p), s);
 }

@@ -1283,8 +1283,8 @@ def test_fused_mx_resblock_pair_c64(lib, dil, mode, M):
 @pytest.mark.parametrize("k,dil,mode,M", [(3, 1, "conv1", 256 * 3), (3, 5, "conv2acc", 256 * 8), (7, 3, "conv1", 256 * 9), (7, 1, "conv2", 256 * 17),
                                           (11, 5, "conv1", 256 * 8), (11, 1, "conv2acc", 256 * 5), (3, 1, "up", 256 * 8)])
 def test_conv_c64_mx(lib, k, dil, mode, M):
-    """conv_c64_mx_kernel (ev_conv64_mx.h): the stage-2 convs (C = 64) in the MX arithmetic on plane sets -- two taps per fp4 MFMA, output
-    channels split over two work items; tile counts that are / are not multiples of 8 (padded work items must store nothing, also with
+    """conv_c64_mx_kernel (ev_conv64_mx.h) and, for k = 7 / 11, conv_gemm_mx64_kernel (ev_gemm_mx64.h): the stage-2 convs (C = 64) in the MX arithmetic on plane
+    sets -- two taps per fp4 MFMA; persistent kernel: output channels split over two work items; tile counts that are / are not multiples of 8 (padded work items must store nothing, also with
     the in-place accumulate).  The input plane set comes from the host quantiser (mxfp4.py); fp64 references: the same arithmetic (tight) and
     the exact conv (the MX error level).  Outputs: fp32 rows and / or the plane set of lrelu(result), which must equal the host quantiser
     applied to the fp32 rows bit for bit."""
@@ -1317,59 +1317,62 @@ def test_conv_c64_mx(lib, k, dil, mode, M):
     res = torch.randn(M, Cc, device="cuda")
     acc = torch.randn(M, Cc, device="cuda")
     want32 = mode != "conv1"                                            # conv1 of a pair writes its result as planes only
-    out = acc.clone() if mode == "conv2acc" else torch.full((M, Cc), 7.0, device="cuda")
-    ps = _PlaneSet(M, Cc)                                               # (its scale planes: [1][rows][4])
-    d = _ffi.ev_conv_gemm_desc()
-    d.dtype, d.A, d.lda, d.W, d.W_lo, d.W_mx = 3, d_h[PAD:].data_ptr(), Cc, d_hi.data_ptr(), d_lo.data_ptr(), d_mx.data_ptr()
-    d.mx_x4[0], d.mx_x4[1] = d_q[0][PAD:].data_ptr(), d_q[1][PAD:].data_ptr()
-    d.mx_xs[0], d.mx_xs[1], d.mx_xs_stride = d_s[0][PAD:].data_ptr(), d_s[1][PAD:].data_ptr(), R * 4
-    d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), M, Cc, Cc, k, dil, (k - 1) // 2, 1.0
-    d.row_valid, d.valid_shift = valid.data_ptr(), 3
-    if mode == "conv1":
-        d.act, d.act_slope = 3, 0.1
-    if mode.startswith("conv2"):
-        d.res, d.res_dtype, d.ldres, d.out_scale = res.data_ptr(), 1, Cc, 1.0 / 3.0
-        if mode == "conv2acc":
-            d.acc32, d.ldacc = out.data_ptr(), Cc
-    if want32:
-        d.out32 = out.data_ptr()
-    d.ldo = Cc
-    planes_out = mode in ("conv1", "conv2")
-    if planes_out:
-        ps.out_fields(d, 1.0 if mode == "conv1" else 0.1)
-        d.mxo_logC = 6
-    _launch(lib, d)
-    h = dil * (k - 1) // 2
-    rows = slice(PAD - h, PAD + M + h)
-    refs = {"emu": _conv64(ah[rows], whd, dil, k) + _conv64(qah[rows], wql, dil, k) + _conv64(qal[rows], wqh, dil, k),
-            "exact": _conv64(full.double()[rows], we, dil, k)}
-    vr = vrow.cpu()
-    for name in refs:
-        y = refs[name] + bias.double().cpu()
+    # k = 7 / 11: both kernels that can run the launch -- the streamed conv_gemm_mx64_kernel (the launcher's choice) and the persistent conv_c64_mx_kernel (reserved0 bit 3)
+    for r0 in ((0, 8) if k > 3 else (0,)):
+        out = acc.clone() if mode == "conv2acc" else torch.full((M, Cc), 7.0, device="cuda")
+        ps = _PlaneSet(M, Cc)                                               # (its scale planes: [1][rows][4])
+        d = _ffi.ev_conv_gemm_desc()
+        d.dtype, d.A, d.lda, d.W, d.W_lo, d.W_mx = 3, d_h[PAD:].data_ptr(), Cc, d_hi.data_ptr(), d_lo.data_ptr(), d_mx.data_ptr()
+        d.mx_x4[0], d.mx_x4[1] = d_q[0][PAD:].data_ptr(), d_q[1][PAD:].data_ptr()
+        d.mx_xs[0], d.mx_xs[1], d.mx_xs_stride = d_s[0][PAD:].data_ptr(), d_s[1][PAD:].data_ptr(), R * 4
+        d.bias, d.M, d.N, d.K, d.taps, d.dil, d.center, d.out_scale = bias.data_ptr(), M, Cc, Cc, k, dil, (k - 1) // 2, 1.0
+        d.row_valid, d.valid_shift = valid.data_ptr(), 3
         if mode == "conv1":
-            y = _lrelu(y, 0.1)
+            d.act, d.act_slope = 3, 0.1
         if mode.startswith("conv2"):
-            y = (y + res.double().cpu()) / 3.0 + (acc.double().cpu() if mode == "conv2acc" else 0.0)
-        y[~vr] = 0
-        refs[name] = y
-    if want32:
-        got = out.cpu().double()
-        assert float(out[~vrow].abs().max()) == 0.0
-        assert _rel(got, refs["emu"]) < 2e-6, (k, dil, mode, _rel(got, refs["emu"]))
-        assert _rel(got, refs["exact"]) < 1.5e-4, (k, dil, mode, _rel(got, refs["exact"]))
-    if planes_out:
-        gh = ps.h[PAD:PAD + M].float().cpu()
-        gq = [mxfp4.dequantize(ps.q4[i][PAD:PAD + M].cpu().numpy(), ps.qs[i][0, PAD:PAD + M, :2].cpu().numpy(), 32) for i in range(2)]
-        if want32:              # the planes are the host quantiser applied to lrelu(out32, 0.1), bit for bit
-            _, _, _, (h16o, cho, clo, sho, slo) = _mx_act_parts(_lrelu(out.cpu(), 0.1))
-            assert np.array_equal(ps.h[PAD:PAD + M].cpu().numpy().view(np.uint16), h16o.view(np.uint16))
-            for i, (codes, sb) in enumerate(((cho, sho), (clo, slo))):
-                assert np.array_equal(ps.q4[i][PAD:PAD + M].cpu().numpy(), codes), i
-                assert np.array_equal(ps.qs[i][0, PAD:PAD + M, :2].cpu().numpy(), sb), i
-        else:                   # planes only: hi + Q(lo) reproduces the conv's result to the fp4 step of the remainder (2^-11 x 0.25)
-            rec = gh.double() + torch.from_numpy(gq[1]).double()
-            assert _rel(rec, refs["emu"]) < 1e-4, (k, dil, mode, _rel(rec, refs["emu"]))
-            assert _rel(gh.double(), refs["emu"]) < 6e-4 and not ps.h[PAD:PAD + M].cpu().numpy()[~vr.numpy()].any()
+            d.res, d.res_dtype, d.ldres, d.out_scale = res.data_ptr(), 1, Cc, 1.0 / 3.0
+            if mode == "conv2acc":
+                d.acc32, d.ldacc = out.data_ptr(), Cc
+        if want32:
+            d.out32 = out.data_ptr()
+        d.ldo = Cc
+        planes_out = mode in ("conv1", "conv2")
+        if planes_out:
+            ps.out_fields(d, 1.0 if mode == "conv1" else 0.1)
+            d.mxo_logC = 6
+        d.reserved0 = r0
+        _launch(lib, d)
+        h = dil * (k - 1) // 2
+        rows = slice(PAD - h, PAD + M + h)
+        refs = {"emu": _conv64(ah[rows], whd, dil, k) + _conv64(qah[rows], wql, dil, k) + _conv64(qal[rows], wqh, dil, k),
+                "exact": _conv64(full.double()[rows], we, dil, k)}
+        vr = vrow.cpu()
+        for name in refs:
+            y = refs[name] + bias.double().cpu()
+            if mode == "conv1":
+                y = _lrelu(y, 0.1)
+            if mode.startswith("conv2"):
+                y = (y + res.double().cpu()) / 3.0 + (acc.double().cpu() if mode == "conv2acc" else 0.0)
+            y[~vr] = 0
+            refs[name] = y
+        if want32:
+            got = out.cpu().double()
+            assert float(out[~vrow].abs().max()) == 0.0
+            assert _rel(got, refs["emu"]) < 2e-6, (k, dil, mode, _rel(got, refs["emu"]))
+            assert _rel(got, refs["exact"]) < 1.5e-4, (k, dil, mode, _rel(got, refs["exact"]))
+        if planes_out:
+            gh = ps.h[PAD:PAD + M].float().cpu()
+            gq = [mxfp4.dequantize(ps.q4[i][PAD:PAD + M].cpu().numpy(), ps.qs[i][0, PAD:PAD + M, :2].cpu().numpy(), 32) for i in range(2)]
+            if want32:              # the planes are the host quantiser applied to lrelu(out32, 0.1), bit for bit
+                _, _, _, (h16o, cho, clo, sho, slo) = _mx_act_parts(_lrelu(out.cpu(), 0.1))
+                assert np.array_equal(ps.h[PAD:PAD + M].cpu().numpy().view(np.uint16), h16o.view(np.uint16))
+                for i, (codes, sb) in enumerate(((cho, sho), (clo, slo))):
+                    assert np.array_equal(ps.q4[i][PAD:PAD + M].cpu().numpy(), codes), i
+                    assert np.array_equal(ps.qs[i][0, PAD:PAD + M, :2].cpu().numpy(), sb), i
+            else:                   # planes only: hi + Q(lo) reproduces the conv's result to the fp4 step of the remainder (2^-11 x 0.25)
+                rec = gh.double() + torch.from_numpy(gq[1]).double()
+                assert _rel(rec, refs["emu"]) < 1e-4, (k, dil, mode, _rel(rec, refs["emu"]))
+                assert _rel(gh.double(), refs["emu"]) < 6e-4 and not ps.h[PAD:PAD + M].cpu().numpy()[~vr.numpy()].any()
     assert _rel(refs["emu"], refs["exact"]) > 1e-6
     # the two-group schedule (conv_c64_mx2_kernel, the launcher's choice above) against the lock-step kernel (reserved0 bit 2): the same arithmetic
     # per output element, so every output must agree bit for bit
@@ -1382,7 +1385,7 @@ def test_conv_c64_mx(lib, k, dil, mode, M):
     if planes_out:
         ps2.out_fields(d, 1.0 if mode == "conv1" else 0.1)
         d.mxo_logC = 6
-    d.reserved0 = 4
+    d.reserved0 = 4 | (8 if k > 3 else 0)          # (k = 7 / 11: `out` / `ps` are the persistent kernel's, the loop's last pass)
     _launch(lib, d)
     if want32:
         assert torch.equal(out, out2), (k, dil, mode)
