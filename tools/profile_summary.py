@@ -56,7 +56,8 @@ FAMILIES = {
     "conv_gemm_mx_vocoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][N_DEC_MX:],
     "conv_gemm_mx_decoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][:N_DEC_MX],
     # (round 4: the two-group variants conv_c64_mx2_kernel / resblock_pair_c32_mx2_kernel are the launchers' default; the fused C = 64 / k = 3 pair)
-    "conv_c64_mx": lambda f: [r for r in f if "conv_c64_mx" in r["Kernel_Name"]],
+    # (round 4, second half: the k = 7 / 11 launches of stage 2 run on the streamed conv_gemm_mx64_kernel, the k = 3 up-conv on the persistent conv_c64_mx kernels)
+    "conv_c64_mx": lambda f: [r for r in f if "conv_c64_mx" in r["Kernel_Name"] or "conv_gemm_mx64_kernel" in r["Kernel_Name"]],
     "resblock_pair_c64_mx": lambda f: [r for r in f if "resblock_pair_c64_mx" in r["Kernel_Name"]],
     "resblock_pair_c32_mx": lambda f: [r for r in f if "resblock_pair_c32_mx" in r["Kernel_Name"]],
     "attention_mfma_x3_lds": lambda f: [r for r in f if "attention_mfma_x3_lds_kernel" in r["Kernel_Name"]],
