@@ -495,7 +495,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU per (sub-)batch (default: 32 / 256 / 128 by mode)")
     ap.add_argument("--sub-batches", type=int, default=0, help="am_vocoder: sub-batches per step (default 1 at N = 1, 8 at N > 1 = configs[3])")
     ap.add_argument("--phonemes", type=int, default=256)
-    ap.add_argument("--cpu-utts", type=int, default=8, help="utterances for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=12, help="utterances for the CPU baseline sample (0 = skip); 12 x 256 phonemes = 12-15 s of host work on 16 threads")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU baseline (more are slower on the 2 x 64-core box)")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch table of the profiled step to this path (+ .<mode> for the other precisions)")
     ap.add_argument("--chunk-mb", type=int, default=0, help="ev_config.vocoder_chunk_mb (tuning; 0 = whole tensors)")
