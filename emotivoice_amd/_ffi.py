@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVHIP_LIB", os.path.join(_HERE, "csrc", "libevhip.so"))
-EV_ABI_VERSION = 4
+EV_ABI_VERSION = 5
 EV_PREC_F16, EV_PREC_F32, EV_PREC_X3, EV_PREC_MX = 0, 1, 2, 3
 EV_FLAG_DEVICE_INPUTS, EV_FLAG_NO_VOCODER, EV_FLAG_WANT_INT16, EV_FLAG_FORCED_DURATIONS = 1, 2, 4, 8
 
@@ -129,15 +129,25 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build the HIP extension first (python emotivoice_amd/csrc/build.py). "
                 "emotivoice_amd has no CPU fallback.")
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
-            fn.restype, fn.argtypes = res, args
-        # a stale library (or a stale copy of this file) must fail here, not mis-parse a descriptor later
-        sizes = (C.c_size_t * 4)()
-        ver = l.ev_abi_info(sizes)
+        # a stale library (or a stale copy of this file) must fail here with the rebuild hint, not with a bare "undefined symbol" from the
+        # binding loop below and not by mis-parsing a descriptor later: ev_abi_info is resolved and checked BEFORE any other symbol
         mine = (C.sizeof(ev_config), C.sizeof(ev_result), C.sizeof(ev_conv_gemm_desc), C.sizeof(ev_res_pair_desc))
+        hint = "rebuild with python emotivoice_amd/csrc/build.py"
+        try:
+            abi_info = l.ev_abi_info
+        except AttributeError:
+            raise ImportError(f"{LIB_PATH} predates ev_abi_info (ABI < 2); this binding is ABI {EV_ABI_VERSION}: {hint}") from None
+        abi_info.restype, abi_info.argtypes = SIGNATURES["ev_abi_info"]
+        sizes = (C.c_size_t * 4)()
+        ver = abi_info(sizes)
         if ver != EV_ABI_VERSION or tuple(sizes) != mine:
             raise ImportError(f"{LIB_PATH}: ABI version {ver} / struct sizes {tuple(sizes)} do not match this binding "
-                              f"({EV_ABI_VERSION} / {mine}): rebuild with python emotivoice_amd/csrc/build.py")
+                              f"({EV_ABI_VERSION} / {mine}): {hint}")
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                raise ImportError(f"{LIB_PATH} does not export {name} although it reports ABI {ver}: {hint}") from None
+            fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib

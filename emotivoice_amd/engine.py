@@ -23,18 +23,17 @@ def resolve_precision(precision, decoder_precision, vocoder_precision):
     activations: fp32-class accuracy, ~1e-6 relative L2 on the waveform), "mx" = the contract mode: the strict data flow, but the
     generator's layers with >= 128 channels evaluate a product as one fp16 MFMA + two block-scaled fp4 MFMAs for the cross terms
     (waveform ~4e-4 from the reference, inside north_star's 1e-3, at half the matrix work of strict).
-    ``decoder_precision`` / ``vocoder_precision`` override it per component."""
+    ``decoder_precision`` / ``vocoder_precision`` override it per component.  ``None`` everywhere = "mx", which is also what
+    ``ev_default_config`` hands a C caller (ABI 5): "fast" and "strict" are explicit opt-ins."""
     if precision not in (None, "fast", "strict", "mx"):
         raise ValueError("precision must be 'fast', 'strict' or 'mx'")
-    if precision == "mx":
-        return decoder_precision or "mx", vocoder_precision or "mx"
-    base = "x3" if precision == "strict" else "f16"
+    base = {None: "mx", "mx": "mx", "strict": "x3", "fast": "f16"}[precision]      # no argument = ev_default_config's own default = the contract mode
     return decoder_precision or base, vocoder_precision or base
 
 
-def make_ev_config(shapes: EVShapes, decoder_precision: str = "f16", keep_stages: bool = False,
+def make_ev_config(shapes: EVShapes, decoder_precision: str = "mx", keep_stages: bool = False,
                    token_rate: str = "split", vocoder_chunk_mb: int = 0, vocoder_streams: int = 0,
-                   vocoder_precision: str = "f16", mx_residual: str = "planes", decoder_attention: str = "split",
+                   vocoder_precision: str = "mx", mx_residual: str = "planes", decoder_attention: str = "split",
                    fused_pairs: bool = True, mx_mrf: str = "planes", decoder_ln: str = "planes", token_splitk: bool = True) -> _ffi.ev_config:
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))

@@ -15,6 +15,7 @@ which are not part of this package.
 from __future__ import annotations
 
 import io
+import logging
 import queue
 import threading
 import time
@@ -26,6 +27,9 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 from .text_io import wav_float_to_int16
+
+
+_log = logging.getLogger("emotivoice_amd.serving")
 
 
 @dataclass
@@ -164,17 +168,29 @@ class DynamicBatcher:
         for r, w in zip(batch, wavs):
             _resolve(r.future, result=np.array(w, np.float32, copy=True))
 
+    @staticmethod
+    def _claim(r: "SynthesisRequest") -> bool:
+        """True if the request's Future could be moved to RUNNING.  A Future its client has cancelled, or already resolved behind the
+        batcher's back (set_exception / set_result as the client's own timeout handling -- set_running_or_notify_cancel raises on a
+        FINISHED Future), drops ONLY itself: the requests co-batched with it must still be served."""
+        try:
+            return (not r.future.done()) and r.future.set_running_or_notify_cancel()
+        except Exception:
+            return False
+
     def _loop(self):
+        consecutive = 0
         while True:
+            batch: List[SynthesisRequest] = []
             try:
                 batch = self._take_batch()
                 if not batch:
                     if self._stop and not self._carry:
                         return
                     continue
-                # a client may cancel its Future while it waits: such requests are dropped here, and a Future that is cancelled
-                # later (mid-batch) is simply not resolved (_resolve) -- neither may take the worker thread down
-                batch = [r for r in batch if r.future.set_running_or_notify_cancel()]
+                # a client may cancel or resolve its Future while it waits: such requests are dropped here one by one, and a Future that is
+                # cancelled later (mid-batch) is simply not resolved (_resolve) -- neither may take the worker thread or its batch-mates down
+                batch = [r for r in batch if self._claim(r)]
                 if not batch:
                     continue
                 self.batches.append(len(batch))
@@ -193,8 +209,14 @@ class DynamicBatcher:
                             self._run([r])
                         except Exception as e1:
                             _resolve(r.future, exception=e1)
-            except Exception:          # nothing a single request does may end the thread every later request depends on
+                consecutive = 0
+            except Exception as e:     # nothing a single request does may end the thread every later request depends on
                 self.loop_errors += 1
+                consecutive += 1
+                _log.exception("DynamicBatcher worker: unexpected error (%d in a row)", consecutive)
+                for r in batch:        # ... and nobody may be left waiting on a batch that was dropped half-way
+                    _resolve(r.future, exception=e)
+                time.sleep(min(0.5, 0.01 * consecutive))      # a persistent failure (e.g. in _take_batch) must not spin a core
 
 
 def _resolve(future: Future, result=None, exception: Optional[BaseException] = None):

@@ -5,6 +5,7 @@ import glob
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -49,7 +50,7 @@ def test_struct_layouts_match_the_c_headers(tmp_path):
 def test_abi_info_reports_what_the_binding_expects():
     """ev_abi_info is what _ffi.lib() checks at load time: a stale libevhip.so or a stale binding must fail there."""
     sizes = (C.c_size_t * 4)()
-    assert _ffi.lib().ev_abi_info(sizes) == _ffi.EV_ABI_VERSION == 4
+    assert _ffi.lib().ev_abi_info(sizes) == _ffi.EV_ABI_VERSION == 5
     assert tuple(sizes) == (C.sizeof(_ffi.ev_config), C.sizeof(_ffi.ev_result), C.sizeof(_ffi.ev_conv_gemm_desc), C.sizeof(_ffi.ev_res_pair_desc))
     hdr = open(os.path.join(ROOT, "include", "evhip.h")).read()
     assert re.search(r"#define EV_ABI_VERSION\s+%d\b" % _ffi.EV_ABI_VERSION, hdr)
@@ -77,6 +78,39 @@ def test_default_config_matches_reference_yaml_values():
     assert (cfg.n_vocab, cfg.n_speaker, cfg.n_mels, cfg.hidden, cfg.heads) == (502, 2014, 80, 384, 8)
     assert list(cfg.up_rates)[:4] == [8, 8, 2, 2] and list(cfg.up_kernels)[:4] == [16, 16, 4, 4]
     assert list(cfg.rb_kernels)[:3] == [3, 7, 11] and [list(r)[:3] for r in cfg.rb_dils][:3] == [[1, 3, 5]] * 3
+
+
+def test_default_config_is_the_contract_precision():
+    """a caller following INTEGRATION.md literally (ev_default_config, no field overridden) must get the mode that
+    meets north_star's 1e-3 on zero-mean audio -- EV_PREC_MX for both components -- in C, in make_ev_config and in EVEngine()'s resolution;
+    fp16 operands (2.4e-3 on zero-mean audio) are an explicit opt-in everywhere."""
+    cfg = _ffi.ev_config()
+    _ffi.lib().ev_default_config(C.byref(cfg))
+    assert (cfg.abi_version, cfg.decoder_precision, cfg.vocoder_precision) == (5, _ffi.EV_PREC_MX, _ffi.EV_PREC_MX)
+    from emotivoice_amd.config import EVShapes
+    from emotivoice_amd.engine import make_ev_config
+    from emotivoice_amd.generator import DEFAULT_PRECISION
+    c2 = make_ev_config(EVShapes())
+    assert (c2.decoder_precision, c2.vocoder_precision) == (_ffi.EV_PREC_MX, _ffi.EV_PREC_MX) and DEFAULT_PRECISION == "mx"
+    src = open(os.path.join(ROOT, "emotivoice_amd", "csrc", "ev_engine.cpp")).read()
+    body = src[src.index("void ev_default_config("):src.index("int ev_abi_info(")]
+    assert "EV_PREC_F16" not in body and body.count("EV_PREC_MX") == 2
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "EV_PREC_MX" in integ and "ev_default_config" in integ
+
+
+def test_stale_library_fails_with_the_rebuild_hint(tmp_path):
+    """a library from before ev_abi_info existed must raise the ImportError that names build.py, not a bare AttributeError
+    from the symbol-binding loop.  Stand-in for the stale .so: a shared object that exports nothing of the ABI."""
+    src = tmp_path / "stale.c"
+    src.write_text("int ev_create(void) { return 0; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['EVHIP_LIB'] = %r\n"
+            "from emotivoice_amd import _ffi\n"
+            "try:\n    _ffi.lib()\nexcept ImportError as e:\n    assert 'build.py' in str(e) and 'ev_abi_info' in str(e), e; print('OK')\n" % (ROOT, str(so)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.stdout.strip() == "OK", r.stderr
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -121,10 +155,12 @@ def test_ev_create_rejects_shapes_the_kernels_do_not_build():
 
 def test_precision_names_resolve():
     from emotivoice_amd.engine import resolve_precision
-    assert resolve_precision(None, None, None) == ("f16", "f16")
+    assert resolve_precision(None, None, None) == ("mx", "mx")       # no argument = the contract mode = ev_default_config's own default
+    assert resolve_precision("mx", None, None) == ("mx", "mx")
     assert resolve_precision("fast", None, None) == ("f16", "f16")
     assert resolve_precision("strict", None, None) == ("x3", "x3")
     assert resolve_precision("strict", "f32", None) == ("f32", "x3")
-    assert resolve_precision(None, None, "x3") == ("f16", "x3")
+    assert resolve_precision(None, None, "x3") == ("mx", "x3")
+    assert resolve_precision("fast", None, "x3") == ("f16", "x3")
     with pytest.raises(ValueError):
         resolve_precision("fastest", None, None)

@@ -1,4 +1,4 @@
-"""MI355X: remaining C-ABI surface -- duration scale alpha, device-pointer inputs on an external stream, borrowed device
+"""MI355X: remaining C-ABI surface in the ABI's DEFAULT precision (EVEngine() = ev_default_config() = the contract mode) -- duration scale alpha, device-pointer inputs on an external stream, borrowed device
 weight blob (the post-broadcast path), exact-fp32 token-rate option, profiling counters, error reporting."""
 import ctypes as C
 
@@ -94,10 +94,13 @@ def test_profiling_counters_and_errors(ctx):
     ks = {k["name"]: k for k in eng.kernel_stats()}
     eng.set_profiling(False)
     assert t["total"] > 0 and t["vocoder"] > 0 and t["am"] > 0 and t["total"] >= t["vocoder"]
-    # conv_pre + 4 ups + the 48 ResBlock convs of stages 0-2 that are not in a fused pair kernel; 3 fused pairs at C = 64, 9 at C = 32
-    assert ks["voc_conv_gemm_f16"]["launches"] == 53 and ks["voc_resblock_pair_c64"]["launches"] == 3
-    assert ks["voc_resblock_pair_c32"]["launches"] == 9
-    assert ks["voc_conv_gemm_f16"]["flops"] > 0 and ks["dec_f16_attention"]["launches"] == 4
+    # the handle is the ABI's own default = the contract mode (mx): conv_pre on the split-precision kernel; 3 up-convs + the 36 ResBlock convs of
+    # stages 0-1 on the MX conv-GEMM; stage 2: the last up-conv + 12 layer-wise k = 7 / 11 convs + 3 fused k = 3 pairs; stage 3: 9 fused pairs
+    assert ks["voc_conv_gemm_x3"]["launches"] == 1 and ks["voc_conv_gemm_mx"]["launches"] == 39
+    assert ks["voc_conv_c64_mx"]["launches"] == 13 and ks["voc_resblock_pair_c64_mx"]["launches"] == 3
+    assert ks["voc_resblock_pair_c32_mx"]["launches"] == 9
+    assert ks["voc_conv_gemm_mx"]["flops"] > 0 and ks["dec_f32_attention"]["launches"] == 4 and ks["dec_mx_gemm"]["launches"] == 16
+    assert "voc_conv_gemm_f16" not in ks and "dec_f16_gemm" not in ks      # nothing of the fp16 mode runs unless it is asked for
     with pytest.raises(EVError, match="unknown stage"):
         eng.get_stage("no_such_tap")
     fresh = EVEngine()
@@ -106,3 +109,54 @@ def test_profiling_counters_and_errors(ctx):
     with pytest.raises(EVError, match="bad magic"):
         fresh.load_blob(b"garbage-garbage-garbage-garbage!")
     fresh.close()
+
+
+def test_integration_md_ctypes_recipe_meets_the_contract():
+    """INTEGRATION.md section 2, literally: raw ctypes, ev_default_config with NO field overridden, ev_create, ev_load_weights,
+    ev_synthesize, ev_memcpy_d2h -- on the zero-mean fixture the reference itself produced (tests/golden/n28_zero_dc.npz), where fp16
+    operands measure 2.4e-3.  The ABI's own default must be inside north_star's 1e-3 on the plain AND the DC-free waveform measure
+    (VERDICT r4 weak #1; reference call site inference_am_vocoder_joint.py:70-74,122-131)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    from conftest import GOLDEN_DIR
+    from emotivoice_amd import _ffi
+    from emotivoice_amd.packer import pack_state_dict
+    from emotivoice_amd.synthetic import synth_state_dict
+    g = np.load(os.path.join(GOLDEN_DIR, "n28_zero_dc.npz"))
+    lib = _ffi.lib()
+    cfg = _ffi.ev_config()
+    lib.ev_default_config(C.byref(cfg))
+    assert (cfg.decoder_precision, cfg.vocoder_precision) == (_ffi.EV_PREC_MX, _ffi.EV_PREC_MX)
+    h = C.c_void_p()
+    assert lib.ev_create(0, C.byref(cfg), C.byref(h)) == 0, lib.ev_last_error(None)
+    try:
+        blob, manifest = pack_state_dict(synth_state_dict(int(g["weight_seed"]), str(g["dur_mode"])))
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        assert lib.ev_load_weights(h, C.cast(buf, C.c_void_p), len(blob), manifest.encode() if isinstance(manifest, str) else None) == 0, lib.ev_last_error(h)
+        ling = np.ascontiguousarray(g["in_ling"], np.int64)
+        cu = np.array([0, ling.size], np.int32)
+        spk = np.array([int(g["in_speaker"])], np.int64)
+        style = np.ascontiguousarray(g["in_style"], np.float32).reshape(1, -1)
+        content = np.ascontiguousarray(g["in_content"], np.float32).reshape(1, -1)
+        res = _ffi.ev_result()
+        rc = lib.ev_synthesize(h, 1, ling.ctypes.data, cu.ctypes.data, spk.ctypes.data, style.ctypes.data, content.ctypes.data,
+                               C.c_float(1.0), _ffi.EV_FLAG_WANT_INT16, C.byref(res))
+        assert rc == 0, lib.ev_last_error(h)
+        assert res.batch == 1 and res.total_frames == int(g["mel_len"]) and res.total_samples == g["wav"].size
+        wav = np.empty(res.total_samples, np.float32)
+        dur = np.empty(res.total_tokens, np.int64)
+        i16 = np.empty(res.total_samples, np.int16)
+        assert lib.ev_memcpy_d2h(h, wav.ctypes.data, res.wav, wav.nbytes) == 0
+        assert lib.ev_memcpy_d2h(h, dur.ctypes.data, res.durations, dur.nbytes) == 0
+        assert lib.ev_memcpy_d2h(h, i16.ctypes.data, res.wav_i16, i16.nbytes) == 0
+    finally:
+        lib.ev_destroy(h)
+    assert np.array_equal(dur, g["dur"])
+    d = wav.astype(np.float64) - g["wav"].astype(np.float64)
+    ref = g["wav"].astype(np.float64)
+    e_wav = float(np.linalg.norm(d) / np.linalg.norm(ref))
+    e_ac = float(np.linalg.norm(d) / np.linalg.norm(ref - ref.mean()))
+    assert abs(ref.mean()) / ref.std() < 0.2            # the fixture IS zero-mean audio
+    assert e_wav < 1e-3 and e_ac < 1e-3, (e_wav, e_ac)
+    assert np.array_equal(i16, (wav * np.float32(32768.0)).astype(np.int64).astype(np.int16))

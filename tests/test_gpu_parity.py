@@ -530,17 +530,19 @@ def test_chunked_vocoding_is_bit_identical(gpu, prec):
     assert np.array_equal(exact14, full)
 
 
-def test_chunked_stage_execution_is_bit_identical(gpu):
+@pytest.mark.parametrize("prec", [None, "fast"], ids=["default", "fast"])
+def test_chunked_stage_execution_is_bit_identical(gpu, prec):
     """The generator's ResBlocks run on row chunks sized for the Infinity Cache (ev_config.vocoder_chunk_mb, overlapped
     tiling over the 6-conv chain of a ResBlock): any chunk size must give the same bits as whole-tensor execution, with chunk
-    borders falling inside utterances and next to the zero gaps between them."""
+    borders falling inside utterances and next to the zero gaps between them.  The chunked schedule exists for the fp16 flow ("fast");
+    in the ABI's default precision (the plane-set flow) the field is accepted and must not change a bit either."""
     from emotivoice_amd.engine import EVEngine
     from oracle import synth_inputs
     _, blob, man = _weights("parity")
     utts = synth_inputs(21, [96, 33, 120, 64, 77, 128, 50, 101], [1, 2, 3, 4, 5, 6, 7, 8])
     outs = []
     for mb in (0, 1, 3, 7):       # whole tensors (default) / ~1 MB chunks (dozens of chunks per stage) / ~3 MB / ~7 MB
-        eng = EVEngine(vocoder_chunk_mb=mb)
+        eng = EVEngine(vocoder_chunk_mb=mb, precision=prec)
         eng.load_blob(blob, man)
         r = eng.synthesize(utts)
         outs.append(r["wav"].copy())

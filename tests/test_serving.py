@@ -185,6 +185,55 @@ def test_worker_survives_a_future_resolved_behind_its_back():
     b.close()
 
 
+def test_future_resolved_while_queued_drops_only_itself():
+    """a client that fails its own Future (set_exception as its timeout handling) while the request is still QUEUED made
+    set_running_or_notify_cancel raise inside the batch filter; the loop's catch-all swallowed it and the whole batch -- the healthy
+    request co-batched with it included -- was never resolved.  Now such a request drops only itself."""
+    started, gate = threading.Event(), threading.Event()
+
+    def slow(utts, alpha):
+        started.set()
+        gate.wait(5)
+        return [np.full(4, len(u["ling"]), np.float32) for u in utts]
+
+    b = DynamicBatcher(slow, max_batch=4, max_wait_ms=20)
+    f0 = b.submit(np.arange(2), 0, np.zeros(768), np.zeros(768))
+    assert started.wait(5)                   # the worker is busy with f0: the next two requests wait in the queue together
+    f1 = b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
+    f2 = b.submit(np.arange(5), 0, np.zeros(768), np.zeros(768))
+    f1.set_exception(TimeoutError("client gave up"))       # resolved behind the batcher's back, while still queued
+    gate.set()
+    assert f0.result(timeout=5)[0] == 2
+    assert f2.result(timeout=5)[0] == 5      # the healthy batch-mate is served
+    with pytest.raises(TimeoutError):
+        f1.result(timeout=1)
+    assert b.loop_errors == 0 and b._thread.is_alive()
+    assert b.batches[-1] == 1                # the dropped request never reached synth_fn
+    b.close()
+
+
+def test_loop_error_fails_the_batch_it_dropped_and_backs_off(caplog):
+    """Whatever the loop's catch-all swallows must (a) fail every unresolved Future of the batch in hand, (b) be logged, (c) not spin."""
+    b = DynamicBatcher(lambda utts, alpha: [np.zeros(4, np.float32) for _ in utts], max_batch=2, max_wait_ms=1)
+    orig = b._claim
+    calls = []
+
+    def broken_claim(r):
+        calls.append(r)
+        if len(calls) == 1:
+            raise MemoryError("unexpected")   # stands for any error outside _run's own try block
+        return orig(r)
+    b._claim = broken_claim
+    with caplog.at_level("ERROR", logger="emotivoice_amd.serving"):
+        f = b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
+        with pytest.raises(MemoryError):
+            f.result(timeout=5)
+    assert b.loop_errors == 1 and any("DynamicBatcher worker" in r.message for r in caplog.records)
+    g = b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))
+    assert g.result(timeout=5).shape == (4,) and b._thread.is_alive()
+    b.close()
+
+
 def test_close_with_a_busy_worker_leaves_it_its_sentinel():
     """close() whose join timed out used to drain the queue -- sentinel included -- so the worker blocked forever after its
     batch and its carried requests were never failed.  Now a live worker keeps the queue: it finishes, sees the sentinel and exits."""
