@@ -40,7 +40,7 @@ class JETSGeneratorHIP:
         """``precision``: "mx" (the contract mode: waveform within 1e-3 of the reference on every fixture; one fp16 MFMA + two
         block-scaled fp4 MFMAs per product), "fast" (fp16 MFMA operands and activations: 2x the speed, 2.4e-3 on zero-mean audio) or
         "strict" (split precision, ~1e-6).  With no precision argument at all the drop-in object runs "mx", so that the one-line swap
-        described in INTEGRATION.md meets the 1e-3 contract without a flag (the low-level EVEngine keeps its "fast" default).
+        described in INTEGRATION.md meets the 1e-3 contract without a flag (EVEngine() and the C ABI's ev_default_config resolve to the same mode since ABI 5).
         See engine.resolve_precision."""
         if precision is None and decoder_precision is None and vocoder_precision is None:
             precision = DEFAULT_PRECISION

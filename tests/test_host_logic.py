@@ -114,8 +114,8 @@ def test_generator_default_precision_is_the_contract_mode():
     g = JETSGeneratorHIP(None, precision="fast")
     assert resolve_precision(g._precision, g._dec_prec, g._voc_prec) == ("f16", "f16")
     g = JETSGeneratorHIP(None, vocoder_precision="x3")
-    assert resolve_precision(g._precision, g._dec_prec, g._voc_prec) == ("f16", "x3")
-    assert resolve_precision(None, None, None) == ("f16", "f16")          # EVEngine itself keeps the fp16 default
+    assert resolve_precision(g._precision, g._dec_prec, g._voc_prec) == ("mx", "x3")      # the unnamed component stays in the contract mode
+    assert resolve_precision(None, None, None) == ("mx", "mx")            # EVEngine() and ev_default_config (ABI 5) agree with the drop-in object
     with pytest.raises(ValueError):
         resolve_precision("fp8", None, None)
 
