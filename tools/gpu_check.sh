@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box via:  gpurun --timeout 2400 -- 'bash tools/gpu_check.sh [stage...]'
-# Stages: ops parity smoke bench prof    (default: ops parity smoke bench)
+# Stages: ops parity gen smoke bench ubench prof pmc pmccal pmcsq dist2    (default: ops parity smoke bench)
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 STAGES="${@:-ops parity smoke bench}"
@@ -31,6 +31,9 @@ for st in $STAGES; do
             timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_cal_write" -o c -- python "$GRAFT_REPO_ROOT/tools/pmc_calibrate.py" > "$GRAFT_REPO_ROOT/gpurun_out/pmc_cal_write.log" 2>&1
             echo "pmccal rc=$?"; cd "$GRAFT_REPO_ROOT";;
     dist2)  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --force-device 0 --batch 8 > gpurun_out/dist2.log 2>&1; echo "dist2 rc=$?"; tail -n 3 gpurun_out/dist2.log | cut -c1-600;;
+    ubench) # stand-alone micro-benchmarks / hardware checks built in-tree (hipcc -o tools/build/<name> tools/<name>.hip): layout A/B of the plane sets,
+            # the K32 -> K16 MFMA chain check; each prints its own verdict line
+            for exe in tools/build/*; do [ -x "$exe" ] && timeout 300 "$exe" > "gpurun_out/ubench_$(basename $exe).txt" 2>&1; echo "ubench $(basename $exe) rc=$?"; tail -n 12 "gpurun_out/ubench_$(basename $exe).txt" | cut -c1-400; done;;
     prof)   cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r1 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --cpu-utts 0 --no-other-precision --voc-streams 1 > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$GRAFT_REPO_ROOT";;
   esac
 done

@@ -1,0 +1,133 @@
+// does a dependent chain  v_mfma_f32_16x16x32_f16 -> legacy v_mfma_f32_16x16x16_f16  on ONE accumulator lose products on the MI355X
+// (DESIGN section 4, round-4 item 6 claimed so after the attention kernel measured 5e-5 ... 4e-4, not repeatable), or was it a missing software wait state?
+//
+// Exact test: operands are small integers (|v| <= 3, sums < 2^11: every fp16 product and fp32 sum is exact), the expected accumulator is computed on
+// the host in integers.  Every variant runs the chain  acc = 0; acc = K32(a, b, acc); acc = K16(a2, b2, acc); [hi/lo style second accumulator likewise]
+// many times per wave with operands re-read from memory, 4 waves per SIMD resident, and counts accumulator words that differ from the expectation:
+//   builtin      both MFMAs as compiler builtins (hipcc pads by its own hazard table)
+//   asm0         both as inline asm, in place ("+v"), NOTHING between them (what an asm kernel without the fence would do), 20 wait states before the read
+//   asmN         the same with s_nop N between the two MFMAs (N = 3, 7, 15)
+//   asm_noread   asm chain, and the accumulator read by a VALU op after only 2 wait states (the round-3 bug of ev_pair_mx.h, as a positive control: this
+//                one is EXPECTED to fail sometimes -- it shows the test can see a lost product)
+//   k32k32       control: two K = 32 MFMAs (second with a zero half), the form the attention kernel ships
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/build/mfma_chain_check tools/mfma_chain_check.hip && tools/build/mfma_chain_check
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+enum { V_BUILTIN = 0, V_ASM0, V_ASM3, V_ASM7, V_ASM15, V_ASM_NOREAD, V_K32K32, NVAR };
+static const char* VNAME[NVAR] = {"builtin K32->K16", "asm K32->K16, 0 states between", "asm, s_nop 3 between", "asm, s_nop 7 between", "asm, s_nop 15 between",
+                                  "asm, VALU read after 2 states (positive control)", "builtin K32->K32 (shipped form)"};
+
+template <int VAR>
+__global__ __launch_bounds__(256, 4) void chain_kernel(const h8* __restrict__ A, const h8* __restrict__ B, const h4* __restrict__ A2, const h4* __restrict__ B2,
+                                                       f4* __restrict__ out, int iters, int nsets) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    f4 sum = f4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        const int set = (gw + it) % nsets;
+        const h8 a = A[set * 64 + lane], b = B[set * 64 + lane];
+        const h4 a2 = A2[set * 64 + lane], b2 = B2[set * 64 + lane];
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (VAR == V_BUILTIN) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, b2, acc, 0, 0, 0);
+        } else if constexpr (VAR == V_K32K32) {
+            const h4 z = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            const h8 a2w = __builtin_shufflevector(a2, z, 0, 1, 2, 3, 4, 5, 6, 7), b2w = __builtin_shufflevector(b2, z, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2w, b2w, acc, 0, 0, 0);
+        } else {
+            // operands are settled (loaded, waited for by the compiler, then two states of distance) before the string starts
+            asm volatile("s_nop 1" ::: "memory");
+            if constexpr (VAR == V_ASM0 || VAR == V_ASM_NOREAD)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\tv_mfma_f32_16x16x16_f16 %0, %3, %4, %0" : "+v"(acc) : "v"(a), "v"(b), "v"(a2), "v"(b2));
+            else if constexpr (VAR == V_ASM3)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 3\n\tv_mfma_f32_16x16x16_f16 %0, %3, %4, %0" : "+v"(acc) : "v"(a), "v"(b), "v"(a2), "v"(b2));
+            else if constexpr (VAR == V_ASM7)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7\n\tv_mfma_f32_16x16x16_f16 %0, %3, %4, %0" : "+v"(acc) : "v"(a), "v"(b), "v"(a2), "v"(b2));
+            else
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\tv_mfma_f32_16x16x16_f16 %0, %3, %4, %0" : "+v"(acc) : "v"(a), "v"(b), "v"(a2), "v"(b2));
+            if constexpr (VAR == V_ASM_NOREAD) asm volatile("s_nop 0" : "+v"(acc));                       // 1 + hipcc's boundary state: too early on purpose
+            else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc));                               // 20 states: the library's mfma_asm_fence
+        }
+        sum += acc * (float)(1 + (it & 3));
+    }
+    out[(size_t)gw * 64 + lane] = sum;
+}
+
+// 16x16x32: lane l holds A[row = l & 15][k = 8 (l >> 4) .. + 8], B[k = 8 (l >> 4) .. + 8][col = l & 15]; 16x16x16: k = 4 (l >> 4) .. + 4.
+// D: lane l holds D[row = 4 (l >> 4) + i][col = l & 15], i = 0..3
+int main() {
+    const int nsets = 64, blocks = 1024 * 4, iters = 400;
+    std::vector<_Float16> A(nsets * 64 * 8), B(nsets * 64 * 8), A2(nsets * 64 * 4), B2(nsets * 64 * 4);
+    std::vector<float> exp_set((size_t)nsets * 64 * 4);
+    unsigned rng = 12345u;
+    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 24) % 7) - 3; };
+    for (int s = 0; s < nsets; ++s) {
+        int a[16][32], b[32][16], a2[16][16], b2[16][16];
+        for (int i = 0; i < 16; ++i) for (int k = 0; k < 32; ++k) { a[i][k] = rnd(); b[k][i] = rnd(); }
+        for (int i = 0; i < 16; ++i) for (int k = 0; k < 16; ++k) { a2[i][k] = rnd(); b2[k][i] = rnd(); }
+        for (int l = 0; l < 64; ++l) {
+            for (int e = 0; e < 8; ++e) { A[(s * 64 + l) * 8 + e] = (_Float16)a[l & 15][8 * (l >> 4) + e]; B[(s * 64 + l) * 8 + e] = (_Float16)b[8 * (l >> 4) + e][l & 15]; }
+            for (int e = 0; e < 4; ++e) { A2[(s * 64 + l) * 4 + e] = (_Float16)a2[l & 15][4 * (l >> 4) + e]; B2[(s * 64 + l) * 4 + e] = (_Float16)b2[4 * (l >> 4) + e][l & 15]; }
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * (l >> 4) + i, c = l & 15;
+                int v = 0;
+                for (int k = 0; k < 32; ++k) v += a[r][k] * b[k][c];
+                for (int k = 0; k < 16; ++k) v += a2[r][k] * b2[k][c];
+                exp_set[((size_t)s * 64 + l) * 4 + i] = (float)v;
+            }
+        }
+    }
+    h8 *dA, *dB; h4 *dA2, *dB2; f4* dout;
+    CHK(hipMalloc(&dA, A.size() * 2)); CHK(hipMalloc(&dB, B.size() * 2)); CHK(hipMalloc(&dA2, A2.size() * 2)); CHK(hipMalloc(&dB2, B2.size() * 2));
+    const size_t nout = (size_t)blocks * 4 * 64;
+    CHK(hipMalloc(&dout, nout * sizeof(f4)));
+    CHK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice)); CHK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(dA2, A2.data(), A2.size() * 2, hipMemcpyHostToDevice)); CHK(hipMemcpy(dB2, B2.data(), B2.size() * 2, hipMemcpyHostToDevice));
+    // expectation per (wave, lane, i): sum over it of exp_set[(gw + it) % nsets] * (1 + (it & 3)): small integers, exact in fp32 (|.| < 2^24)
+    std::vector<float> expect(nout * 4), got(nout * 4);
+    for (size_t gw = 0; gw < (size_t)blocks * 4; ++gw) {
+        if (gw >= (size_t)nsets) {          // the operand sequence of a wave depends on gw % nsets only
+            memcpy(&expect[gw * 256], &expect[(gw % nsets) * 256], 256 * sizeof(float));
+            continue;
+        }
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 4; ++i) {
+                double v = 0;
+                for (int it = 0; it < iters; ++it) v += (double)exp_set[(((gw + it) % nsets) * 64 + l) * 4 + i] * (1 + (it & 3));
+                expect[(gw * 64 + l) * 4 + i] = (float)v;
+            }
+    }
+    int bad_total = 0;
+    for (int var = 0; var < NVAR; ++var) {
+        long bad = 0, runs_bad = 0;
+        for (int rep = 0; rep < 5; ++rep) {
+            CHK(hipMemset(dout, 0, nout * sizeof(f4)));
+            switch (var) {
+#define LAUNCH(V) case V: hipLaunchKernelGGL(chain_kernel<V>, dim3(blocks), dim3(256), 0, 0, dA, dB, dA2, dB2, dout, iters, nsets); break;
+                LAUNCH(V_BUILTIN) LAUNCH(V_ASM0) LAUNCH(V_ASM3) LAUNCH(V_ASM7) LAUNCH(V_ASM15) LAUNCH(V_ASM_NOREAD) LAUNCH(V_K32K32)
+#undef LAUNCH
+            }
+            CHK(hipDeviceSynchronize());
+            CHK(hipMemcpy(got.data(), dout, nout * sizeof(f4), hipMemcpyDeviceToHost));
+            long b = 0;
+            for (size_t i = 0; i < got.size(); ++i) b += got[i] != expect[i];
+            bad += b; runs_bad += b != 0;
+        }
+        printf("%-52s wrong accumulator words: %ld of %zu x 5 runs (%ld runs affected)%s\n", VNAME[var], bad, got.size(), runs_bad,
+               var == V_ASM_NOREAD ? "   [expected to fail: shows the check can see a lost product]" : "");
+        if (var != V_ASM_NOREAD) bad_total += bad != 0;
+    }
+    printf("%s\n", bad_total ? "RESULT: a chain variant other than the positive control lost products" : "RESULT: every K32->K16 chain variant is exact; only the early VALU read (if any) fails");
+    return 0;
+}
