@@ -362,6 +362,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
         q32[nq] = *reinterpret_cast<const h8*>(qp + 8 * fg);
         q16[nq] = *reinterpret_cast<const h4*>(qp + 32 + 4 * fg);
     }
+    const h4 zero4 = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    const h8 q16w[2] = {__builtin_shufflevector(q16[0], zero4, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(q16[1], zero4, 0, 1, 2, 3, 4, 5, 6, 7)};
     const float scale2 = 1.4426950408889634f / sqrtf((float)DK);    // log2(e) / sqrt(d_k): softmax in base 2
 
     // staging: 64 keys x 96 B = 384 16-byte chunks for K and for V; 256 threads -> chunk tid and (tid < 128) chunk tid + 256
@@ -420,11 +422,15 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnParams p)
         for (int kt = 0; kt < 4; ++kt) {
             const h8 ka32 = *reinterpret_cast<const h8*>(Kb + (kt * 16 + fr) * KP + 16 * fg);
             const h4 ka16 = *reinterpret_cast<const h4*>(Kb + (kt * 16 + fr) * KP + 64 + 8 * fg);
+            const h8 ka16w = __builtin_shufflevector(ka16, zero4, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
+                // d_k = 48 = one full K = 32 MFMA + one with a zero half.  NOT a K = 32 followed by the legacy 16x16x16 form on the same accumulator: that
+                // chain loses products on the MI355X unless >= 5 wait states separate the two (tools/mfma_chain_check.hip, profiles/r5_a_mfma_chain_check.txt:
+                // wrong with 0 and 4 states, exact from 5), and hipcc pads its own builtins with none (tests/test_isa_hazards.py keeps such a chain out of the library)
                 f4 z = f4{0.f, 0.f, 0.f, 0.f};
                 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka32, q32[nq], z, 0, 0, 0);
-                s[nq][kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ka16, q16[nq], z, 0, 0, 0);
+                s[nq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka16w, q16w[nq], z, 0, 0, 0);
             }
         }
         h8 pb[2][2];

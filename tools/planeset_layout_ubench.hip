@@ -123,7 +123,8 @@ template <int C, int REC>
 static void run(long rows, const char* what) {
     const int ntiles = (int)(rows / BM);
     const size_t bh = al((size_t)rows * 2 * C), bq = al((size_t)rows * C / 2), bs = al((size_t)(C / 128 > 0 ? C / 128 : 1) * rows * 4);
-    const size_t total = bh + 2 * bq + 2 * bs;
+    size_t total = bh + 2 * bq + 2 * bs;
+    if (total < (size_t)rows * REC + 4096) total = (size_t)rows * REC + 4096;          // the padded records are the larger footprint
     char *din, *dout;
     CHK(hipMalloc(&din, total)); CHK(hipMalloc(&dout, total));
     CHK(hipMemset(din, 1, total)); CHK(hipMemset(dout, 0, total));
