@@ -88,6 +88,20 @@ PARITY_LEVEL = {"mx": "<= 5.5e-4 on every fixture incl. zero-mean and trained-li
 REFERENCE_CPU_FRAMES_PER_S = 628.0                 # the reference's own JETSGenerator, 8 Xeon cores, B = 1, N = 256
 
 
+def reference_cpu_record():
+    """The reference ITSELF timed in the build container (tools/time_reference.py -> profiles/r5_reference_cpu.json, kind "reference"): 64 phonemes =
+    BASELINE configs[0], 256 phonemes = the utterance length of configs[1].  /root/reference cannot travel to the GPU box, so this is a committed
+    measurement quoted beside the live numbers, never `value`."""
+    path = os.path.join(ROOT, "profiles", "r5_reference_cpu.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    out = dict(kind=rec.get("kind"), cores=rec.get("cores"), host=rec.get("host", {}).get("cpu"), source="profiles/r5_reference_cpu.json (tools/time_reference.py, build container)")
+    for k, v in rec.get("results", {}).items():
+        out[k] = dict(frames_per_s=v["frames_per_s"], ms_per_utterance=v["ms_per_utterance_median"], x_realtime=v["x_realtime"])
+    return out
+
+
 def decoder_flops(frames):
     """Algorithmic FLOPs of the 4-layer mel decoder for one utterance of T frames (SURVEY.md section 8(d) formula)."""
     T = float(frames)
@@ -134,7 +148,8 @@ def cpu_baseline(n_utts, phonemes, threads=16):
                 sample="%d utterances x %d phonemes, B=1 loop, fp32 torch-CPU oracle, %.1f s" % (done, phonemes, dt),
                 reference_measured_elsewhere=dict(value=REFERENCE_CPU_FRAMES_PER_S, unit="mel-frames/s", cores=8,
                                                   note="the reference's own JETSGenerator module (kind 'reference') timed in the build "
-                                                       "container, SURVEY.md section 6; /root/reference does not exist on the GPU box"))
+                                                       "container, SURVEY.md section 6; /root/reference does not exist on the GPU box",
+                                                  current=reference_cpu_record()))
 
 
 class Workload:
@@ -214,6 +229,14 @@ def b1_latency(eng, phonemes=(64, 256)):
                 best = min(best, dtl)
         lat["b1_%dph_ms" % nph] = round(best * 1e3, 3)
         lat["b1_%dph_x_realtime" % nph] = round(int(r1.total_frames) * 256 / 16000 / best, 1)
+    # BASELINE configs[0] names the CPU PyTorch reference path at 64 phonemes: the reference's own module, timed in the build container, beside the GPU call
+    ref = reference_cpu_record()
+    if ref:
+        lat["cpu_reference"] = ref
+        for nph in phonemes:
+            r = ref.get("%dph" % nph)
+            if r:
+                lat["b1_%dph_speedup_vs_cpu_reference" % nph] = round(r["ms_per_utterance"] / lat["b1_%dph_ms" % nph], 1)
     return lat
 
 
