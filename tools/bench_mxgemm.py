@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--ks", default="3,7,11")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--valid-shift", type=int, default=-1, help=">= 0: pass a row_valid table (one byte per 2^shift rows, the engine's frame validity: stage 1 = 6, stage 0 = 3) with "
+                    "every 129th 256-row tile all-gap, as in a B = 32 x 1024-frame forward")
     ap.add_argument("--dbg", default="", help="comma list of reserved0 low bits to A/B in one run (8 = one block per tile instead of the persistent tile loop)")
     args = ap.parse_args()
     lib = _ffi.lib()
@@ -45,6 +47,12 @@ def main():
     res = torch.randn(M, Cc, device="cuda", generator=g)
     out = torch.empty(M, Cc, device="cuda")
     bias = torch.zeros(Cc, device="cuda")
+    valid = None
+    if args.valid_shift >= 0:
+        valid = torch.ones(M >> args.valid_shift, dtype=torch.uint8, device="cuda")
+        per_tile = 256 >> args.valid_shift
+        for t in range(128, M // 256, 129):          # the gap tile behind every 128 live ones
+            valid[t * per_tile:(t + 1) * per_tile] = 0
     abl_build = "mxabl" in os.environ.get("EVHIP_LIB", "")
     names = {0: "full"}
     if abl_build:
@@ -74,6 +82,8 @@ def main():
                     d.res_x4, d.res_xs, d.res_xs_stride = rq[1][PAD:].data_ptr(), rs[1][0, PAD:].data_ptr(), R * 4
                 else:
                     d.res, d.res_dtype, d.ldres, d.out32 = res.data_ptr(), 1, Cc, out.data_ptr()
+                if valid is not None:
+                    d.row_valid, d.valid_shift = valid.data_ptr(), args.valid_shift
                 d.reserved0 = (abl << 4) if abl >= 0 else (-1 - abl)
                 for _ in range(6):
                     rc = lib.ev_op_conv_gemm(C.byref(d), None)
