@@ -29,6 +29,10 @@ import time
 
 import numpy as np
 
+# the host driver of the GPU boxes only supports dmabuf IPC: without this RCCL's intra-node transport fails with `hipIpcGetMemHandle: invalid argument`
+# (it is exported on the boxes already; a launcher that builds its own environment must not lose it -- set before torch / HIP load)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
