@@ -385,6 +385,11 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx2_kernel(const Res
     const char* const xgt = xg + xq * 32;
     const int xrow2 = min((ltid >> 2) + 128, G::GR - 1 + 2 * h1 + 2 * H2);      // rows beyond the convs' span re-read the last needed row
     const int drow[3] = {ltid >> 2, (ltid >> 2) + 64, (ltid >> 2) + 128};
+    // (round 5) the third unit of a thread is slab row 128 + lw * 16 + lane / 4: the convs read rows < 128 + 2 (h1 + H2) only, so for the short spans (k = 3: 4-12 rows,
+    // k = 7 at d = 1: 12) whole waves have no third unit to stage -- a wave-uniform skip of its two loads and ~75 VALU of quantiser per tile.  This kernel is bound by the
+    // SIMDs' issue ports, not by HBM or latency: instructions not issued are time saved.  Rows nobody reads stay unwritten; the outputs keep their bits.
+    const bool r4_paths = (e.reserved0 & 8) != 0;          // in-process A/B (tools/bench_pair_mx.py --dbg 8): round 4's instruction stream
+    const bool need3 = r4_paths || lw * 16 < 2 * (h1 + H2);
 #define EV_PMX_ROW(G_) min((G_), gmax + 63)
 #define EV_PMX_GLOAD(TILE)                                                                                 \
     {                                                                                                      \
@@ -395,10 +400,10 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx2_kernel(const Res
         const char* q2_ = xgt + (long)EV_PMX_ROW(g2_) * x_pitch;                                           \
         xr[0][0] = *reinterpret_cast<const float4*>(q0_); xr[0][1] = *reinterpret_cast<const float4*>(q0_ + 16); \
         xr[1][0] = *reinterpret_cast<const float4*>(q1_); xr[1][1] = *reinterpret_cast<const float4*>(q1_ + 16); \
-        xr[2][0] = *reinterpret_cast<const float4*>(q2_); xr[2][1] = *reinterpret_cast<const float4*>(q2_ + 16); \
+        if (need3) { xr[2][0] = *reinterpret_cast<const float4*>(q2_); xr[2][1] = *reinterpret_cast<const float4*>(q2_ + 16); } \
     }
 #define EV_PMX_SSTORE()                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                        \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) if (i < 2 || need3) {                                    \
         f32x2 a_[4] = {lrelu2(f32x2{xr[i][0].x, xr[i][0].y}, slope01), lrelu2(f32x2{xr[i][0].z, xr[i][0].w}, slope01), \
                        lrelu2(f32x2{xr[i][1].x, xr[i][1].y}, slope01), lrelu2(f32x2{xr[i][1].z, xr[i][1].w}, slope01)}; \
         uint4 ho_; unsigned ch_, cl_, bh_, bl_;                                                            \
@@ -497,6 +502,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx2_kernel(const Res
             for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         EV_PMX_CONV(Xh, Xq, Xsc, XR, W1h, 0, dil)
         const unsigned xtmask = (unsigned)vmask;
+        const bool xt_masked = r4_paths || xtmask != 0xffffffffu;          // (round 5) the 16 selects per tile that zero xt outside the utterances run only where there is such a row
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int r1 = wrow0 + b * 16;
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx2_kernel(const Res
                 v[a][1] = lrelu2(f32x2{acc[a][b][2], acc[a][b][3]} + b1v[a][1], slope01);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    v[a][q][0] = valid ? v[a][q][0] : 0.f; v[a][q][1] = valid ? v[a][q][1] : 0.f;
+                    if (xt_masked) { v[a][q][0] = valid ? v[a][q][0] : 0.f; v[a][q][1] = valid ? v[a][q][1] : 0.f; }      // (wave-uniform: only a wave with a row outside the utterances)
                     hh[a][q] = __builtin_convertvector(v[a][q], half2v);
                     hf[a][q] = __builtin_convertvector(hh[a][q], f32x2);
                     lf[a][q] = v[a][q] - hf[a][q];
@@ -569,8 +575,13 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c32_mx2_kernel(const Res
                 v[2] += f32x2{accin[it][1].x, accin[it][1].y}; v[3] += f32x2{accin[it][1].z, accin[it][1].w};
             }
             float* op = rowok ? o32 + (long)t * e.ldo + eco : reinterpret_cast<float*>(trash);
-            *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (outmask == 0xffffffffu && !r4_paths) {          // (round 5, wave-uniform) every output row of the wave is inside an utterance: no selects
+                *reinterpret_cast<float4*>(op) = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
+            } else {
+                *reinterpret_cast<float4*>(op) = valid ? make_float4(v[0][0], v[0][1], v[1][0], v[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(op + 4) = valid ? make_float4(v[2][0], v[2][1], v[3][0], v[3][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         vmask = vmask_next;
         EV_PMX_GROUP_BARRIER()          // the group's new slab is complete; xt may be overwritten
