@@ -160,3 +160,25 @@ def test_integration_md_ctypes_recipe_meets_the_contract():
     assert abs(ref.mean()) / ref.std() < 0.2            # the fixture IS zero-mean audio
     assert e_wav < 1e-3 and e_ac < 1e-3, (e_wav, e_ac)
     assert np.array_equal(i16, (wav * np.float32(32768.0)).astype(np.int64).astype(np.int16))
+
+
+def test_small_batch_three_stream_generator_equals_single_stream_bitwise(ctx):
+    """in the default precision a small batch (<= 2048 frame rows) runs the three ResBlocks of a generator stage on three streams with per-ResBlock
+    plane sets, the running MRF sum ordered by events (stages 0-1: partial plane sets, `mrf_pl`; stages 2-3: the fp32 sum); ev_config.vocoder_streams = 1 keeps
+    everything on the handle's stream.  Same arithmetic, same order of the MRF additions: the waveforms must be bit-identical -- for a single utterance (the
+    reference's own call pattern) and for a batch that crosses into the serial large-batch path."""
+    from emotivoice_amd.engine import EVEngine
+    from emotivoice_amd.synthetic import synth_inputs
+    one = EVEngine(vocoder_streams=1)
+    one.load_blob(ctx["blob"], ctx["man"])
+    assert one.decoder_precision == "mx" and one.vocoder_precision == "mx"
+    for utts in (ctx["utts"][:1], ctx["utts"], synth_inputs(83, [200, 180, 190, 170], [5, 6, 7, 8])):
+        a = ctx["eng"].synthesize(utts)
+        b = one.synthesize(utts)
+        assert np.array_equal(a["durations"], b["durations"]) and np.array_equal(a["mel"], b["mel"])
+        assert np.array_equal(a["wav"], b["wav"]), len(utts)
+    # ... and repeated single-utterance calls on the three-stream path are stable run to run (the event ordering is not a race)
+    first = ctx["eng"].synthesize(ctx["utts"][:1])["wav"].copy()
+    for _ in range(5):
+        assert np.array_equal(ctx["eng"].synthesize(ctx["utts"][:1])["wav"], first)
+    one.close()
