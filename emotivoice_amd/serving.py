@@ -96,7 +96,12 @@ class DynamicBatcher:
             self._q.put(req)
         return req.future
 
-    def close(self, timeout: float = 30.0):
+    def close(self, timeout: float = 30.0) -> bool:
+        """Stop accepting requests, let the worker drain what it has, and fail whatever is left.  Returns True when the worker has exited.
+        False = the join timed out: the worker is still inside ``synth_fn`` (a hung device call, say).  Its queued and carried requests then stay
+        with it -- it fails or serves them if it ever returns; a client must not wait on such a Future without its own timeout (``TTSService.speech``
+        passes one), and the owner of the batcher decides what a wedged engine means for the process (the reference's server has no such state:
+        one synchronous call per request, openaiapi.py:159-184).  ``close`` can be called again later to collect the worker."""
         with self._lock:
             if not self._stop:
                 self._stop = True
@@ -105,7 +110,8 @@ class DynamicBatcher:
         if self._thread.is_alive():
             # the worker is still inside a batch (join timed out): it owns the queue and _carry; the sentinel stays queued, so it exits after
             # draining what it has, and nothing is taken from under it here
-            return
+            _log.error("DynamicBatcher.close: the worker did not finish within %.1f s; %d request(s) stay queued behind it", timeout, self._q.qsize())
+            return False
         # the worker has exited (or died): whatever is still queued or carried must not leave its client waiting
         left = list(self._carry)
         self._carry = []
@@ -118,6 +124,7 @@ class DynamicBatcher:
                 left.append(r)
         for r in left:
             _resolve(r.future, exception=RuntimeError("batcher closed"))
+        return True
 
     def _take_batch(self) -> List[SynthesisRequest]:
         """Block for the first request, then keep collecting until the batch is full, the token budget is reached or

@@ -246,14 +246,14 @@ def test_close_with_a_busy_worker_leaves_it_its_sentinel():
 
     b = DynamicBatcher(slow, max_batch=1, max_wait_ms=1)
     futs = [b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768), alpha=1.0 + i) for i in range(3)]
-    b.close(timeout=0.05)                   # the worker is inside the first batch: join times out
+    assert b.close(timeout=0.05) is False   # the worker is inside the first batch: join times out, and close() says so
     assert b._thread.is_alive()
     gate.set()
     b._thread.join(5)
     assert not b._thread.is_alive()         # it drained its requests, met the sentinel and returned
     for f in futs:
         assert f.done()
-    b.close()                               # idempotent
+    assert b.close() is True                # idempotent; the worker has been collected
 
 
 def test_token_budget_splits_batches():
