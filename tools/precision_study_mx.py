@@ -61,9 +61,28 @@ def mx_quant(v, fmt, dim):
     return qv.reshape(vp.shape)[..., :n].movedim(-1, dim)
 
 
+def mx_quant_lo_fixed(lo, hi, fmt, dim):
+    """Round 5 study: the remainder plane of an ACTIVATION quantised with a scale DERIVED from the hi plane's block scale instead of its own block maximum
+    (|a - fp16(a)| <= 2^-11 2^(e + 1) with e the exponent of the block's largest hi part: scale byte bl = bh - 11) -- saves the producer one block maximum."""
+    lo, hi = lo.movedim(dim, -1), hi.movedim(dim, -1)
+    n = lo.shape[-1]
+    pad = (-n) % 32
+    lp, hp = F.pad(lo, (0, pad)), F.pad(hi, (0, pad))
+    lb, hb = lp.reshape(*lp.shape[:-1], -1, 32), hp.reshape(*hp.shape[:-1], -1, 32)
+    amax = hb.abs().amax(-1, keepdim=True)
+    scale = torch.exp2(torch.floor(torch.log2(amax.clamp_min(1e-38))) - FORMATS[fmt][2] - 11)
+    scale = torch.where(amax > 0, scale, torch.ones_like(scale))
+    qv = quant_elem(lb / scale, fmt) * scale
+    return qv.reshape(lp.shape)[..., :n].movedim(-1, dim)
+
+
+LO_FIXED = [False]          # set per recipe by emulate()
+
+
 class Recipe:
     def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None, mrf16=False,
-                 engine_flow=False, mrf_planes=None):
+                 engine_flow=False, mrf_planes=None, lo_fixed=False):
+        self.lo_fixed = lo_fixed          # activation remainders (operand planes and residual planes) with the derived scale
         self.name, self.cross, self.res32, self.op32, self.lo_terms = name, cross, res32, op32, lo_terms
         # mrf16: the first two scaled ResBlock outputs of a stage are stored in fp16 and added in the third one's fp32 epilogue (the fast mode's MRF sum:
         # 8 bytes less HBM traffic per stage-output element than an fp32 running sum)
@@ -81,7 +100,7 @@ def planes_roundtrip(x, fmt):
     a = F.leaky_relu(x, 0.1)
     h = r16(a)
     lo = a - h
-    lo = r16(lo) if fmt == "f16" else mx_quant(lo, fmt, 1)
+    lo = r16(lo) if fmt == "f16" else (mx_quant_lo_fixed(lo, h, fmt, 1) if LO_FIXED[0] else mx_quant(lo, fmt, 1))
     a2 = h + lo
     return torch.where(a2 >= 0, a2, a2 * 10.0)
 
@@ -102,11 +121,13 @@ def conv_mx(x, w, b, rc, transposed=False, **kw):
     if "xh_wl" in rc.lo_terms:
         y = y + op(qa(xh, 1), qb(wl, kdim_w), None, **kw)
     if "xl_wh" in rc.lo_terms:
-        y = y + op(qa(xl, 1), qb(wh, kdim_w), None, **kw)
+        xlq = mx_quant_lo_fixed(xl, xh, rc.cross, 1) if (LO_FIXED[0] and rc.cross not in (None, "f16")) else qa(xl, 1)
+        y = y + op(xlq, qb(wh, kdim_w), None, **kw)
     return y
 
 
 def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
+    LO_FIXED[0] = bool(getattr(rc, "lo_fixed", False))
     st = (lambda t: t) if rc.res32 else r16              # residual-stream / stage tensors
     if rc.res_planes:
         st = lambda t: planes_roundtrip(t, rc.res_planes)
@@ -197,6 +218,7 @@ def main():
             Recipe("MX-fp4, fp32 residual + fp16 MRF partial sums", "fp4", mrf16=True),
             Recipe("ENGINE r4 + MRF partials as hi + fp4 remainder", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4"),
             Recipe("ENGINE r4 + MRF partials as hi + fp4 remainder, stage 3 from planes too", "fp4", res_planes="fp4", mrf_planes="fp4"),
+            Recipe("ENGINE r4 + MRF partials, remainder scale DERIVED from the hi scale (bl = bh - 11)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", lo_fixed=True),
             Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
             Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
         ]
