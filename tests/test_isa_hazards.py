@@ -17,10 +17,21 @@ import isa_hazard_lint as lint      # noqa: E402
 LIB = os.path.join(ROOT, "emotivoice_amd", "csrc", "libevhip.so")
 
 
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _need_tools(*extra):
+    """These are CPU tests, but they drive the ROCm binutils: skip (not error) on a host without them."""
+    missing = [t for t in (lint.LLVM + "/llvm-objcopy", lint.LLVM + "/clang-offload-bundler", lint.LLVM + "/llvm-objdump") + extra if not os.path.exists(t)]
+    if missing:
+        pytest.skip("ROCm tools not installed: " + ", ".join(missing))
+
+
 @pytest.fixture(scope="module")
 def shipped():
     if not os.path.exists(LIB):
         pytest.skip("libevhip.so not built")
+    _need_tools()
     return lint.run(LIB)
 
 
@@ -71,15 +82,32 @@ extern "C" __global__ void mixed_chain(const h8* a, const h8* b, const h4* a2, c
     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a2[threadIdx.x], b2[threadIdx.x], acc, 0, 0, 0);
     o[threadIdx.x] = acc;
 }
+// partial_srcc: the second MFMA's SrcC (v[22:25]) overlaps the first one's destination (v[20:23]) only partially, one slot behind it
+extern "C" __global__ void partial_srcc(const h8* a, const h8* b, float* o) {
+    float r;
+    asm volatile("v_mfma_f32_16x16x32_f16 v[20:23], %1, %2, 0\n\tv_mfma_f32_16x16x32_f16 v[24:27], %1, %2, v[22:25]\n\t"
+                 "s_nop 7\n\ts_nop 7\n\ts_nop 3\n\tv_mov_b32 %0, v24"
+                 : "=v"(r) : "v"(a[threadIdx.x]), "v"(b[threadIdx.x]) : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");
+    o[threadIdx.x] = r;
+}
+// waw: the second MFMA overwrites the first one's destination (SrcC = 0: no chain) one slot behind it
+extern "C" __global__ void waw(const h8* a, const h8* b, float* o) {
+    float r;
+    asm volatile("v_mfma_f32_16x16x32_f16 v[20:23], %1, %2, 0\n\tv_mfma_f32_16x16x32_f16 v[20:23], %2, %1, 0\n\t"
+                 "s_nop 7\n\ts_nop 7\n\ts_nop 3\n\tv_mov_b32 %0, v20"
+                 : "=v"(r) : "v"(a[threadIdx.x]), "v"(b[threadIdx.x]) : "v20", "v21", "v22", "v23");
+    o[threadIdx.x] = r;
+}
 '''
 
 
 def test_lint_flags_the_known_bad_patterns(tmp_path):
     """The lint must SEE what it is there for: a VALU read two slots behind an asm MFMA, and a K32 -> K16 builtin chain; and pass the fenced form."""
+    _need_tools(HIPCC)
     src = tmp_path / "selftest.hip"
     src.write_text(SELF_TEST)
     obj = tmp_path / "selftest.o"
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     viol, fns = lint.run(str(obj))
     by = {}
@@ -88,5 +116,8 @@ def test_lint_flags_the_known_bad_patterns(tmp_path):
     assert "early_read" in by and by["early_read"][0]["kind"] == "non-MFMA access" and by["early_read"][0]["wait_states"] < 8
     assert "mixed_chain" in by and by["mixed_chain"][0]["kind"] == "accumulate chain across two MFMA opcodes"
     assert "fenced" not in by
+    # (round 6) the partial-SrcC / write-after-write class the docstring promises: p + 3 = 7 states, both kernels sit 0 states behind the producer
+    for k in ("partial_srcc", "waw"):
+        assert k in by and by[k][0]["kind"] == "MFMA partial SrcC / vDst overlap" and by[k][0]["required"] == 7 and by[k][0]["wait_states"] == 0, (k, by.get(k))
     fenced = [v for k, v in fns.items() if k.startswith("fenced")]
     assert fenced and fenced[0]["mfma"] == 1 and (fenced[0]["min_slack"] is None or fenced[0]["min_slack"] >= 0)      # None: no access within the look-ahead

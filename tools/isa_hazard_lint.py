@@ -58,7 +58,20 @@ PASSES = [            # (opcode regex, passes, is_xdl)
 # uniform: measured on the MI355X with exact integer operands (tools/mfma_chain_check.hip, profiles/r5_a_mfma_chain_check.txt, 4 waves / SIMD, 2 x 10^7 words):
 #   v_mfma_f32_16x16x32_f16 <-> legacy v_mfma_f32_16x16x16_f16 : WRONG at 0 and 4 states (also as compiler builtins), exact at 5, 6, 7, 8, 16 -> not in this set
 #   v_mfma_f32_16x16x32_f16 <-> v_mfma_scale_f32_16x16x128_f8f6f4 (fp4 operands): exact at 0 states in both orders -> the MX kernels' pass 0 -> pass 1 hand-over
-CHAIN_MEASURED_OK = {frozenset(("v_mfma_f32_16x16x32_f16", "v_mfma_scale_f32_16x16x128_f8f6f4"))}
+#   the same with an E5M2 (bf8) B operand, `cbsz:4 blgp:1` (round 6, profiles/r6_a_mfma_chain_check.txt): exact at 0 states in both orders, and against the fp4 x fp4 form
+# A block-scaled MFMA's chain key carries its operand formats (cbsz = A, blgp = B: 0 fp8, 1 bf8, 2 fp6, 3 bf6, 4 fp4): a pair is only as good as its measurement.
+MX16 = "v_mfma_scale_f32_16x16x128_f8f6f4"
+CHAIN_MEASURED_OK = {frozenset(("v_mfma_f32_16x16x32_f16", MX16 + " cbsz:4 blgp:4")),
+                     frozenset(("v_mfma_f32_16x16x32_f16", MX16 + " cbsz:4 blgp:1")),
+                     frozenset((MX16 + " cbsz:4 blgp:4", MX16 + " cbsz:4 blgp:1"))}
+
+
+def chain_key(x):
+    """Opcode as the accumulate-chain table sees it: block-scaled MFMAs with their operand formats."""
+    if "f8f6f4" not in x.op:
+        return x.op
+    a, b = re.search(r"cbsz:(\d+)", x.args), re.search(r"blgp:(\d+)", x.args)
+    return "%s cbsz:%s blgp:%s" % (x.op, a.group(1) if a else "0", b.group(1) if b else "0")
 
 
 def mfma_info(op):
@@ -182,6 +195,7 @@ def lint(ins):
                     break
                 touch = y.regs & dst
                 if touch:
+                    need, kind = need_other, "non-MFMA access"          # (per instruction: nothing is inherited from the previous one)
                     if y.op.startswith("v_mfma"):
                         yo = split_operands(y.args)
                         ydst, ya, yb, yc = regs_of(yo[0]), regs_of(yo[1]), regs_of(yo[2]), regs_of(yo[3])
@@ -189,18 +203,20 @@ def lint(ins):
                         if (ya | yb | yscale) & dst:
                             need, kind = need_other, "MFMA SrcA/B/scale"
                         elif yc == dst:
-                            key = "%s -> %s" % (x.op, y.op)
+                            kx, ky = chain_key(x), chain_key(y)
+                            key = "%s -> %s" % (kx, ky)
                             c = st["chains"].setdefault(key, [0, None])
                             c[0] += 1
                             c[1] = ws if c[1] is None else min(c[1], ws)
-                            if y.op == x.op or frozenset((x.op, y.op)) in CHAIN_MEASURED_OK:
+                            if ky == kx or frozenset((kx, ky)) in CHAIN_MEASURED_OK:
                                 need, kind = 0, "chain"
                             else:
                                 # a dependent chain across two opcodes that nobody has measured: priced like any other reader (p + 4), which is where the
                                 # one pair measured BAD (16x16x32 f16 <-> legacy 16x16x16 f16: wrong at 0 and 4 states, exact from 5) is safe with margin
                                 need, kind = need_other, "accumulate chain across two MFMA opcodes"
-                    else:
-                        need, kind = need_other, "non-MFMA access"
+                        else:
+                            # SrcC overlaps the producer's destination only partially, or only vDst does (write after write)
+                            need, kind = need_srcc, "MFMA partial SrcC / vDst overlap"
                     slack = ws - need
                     if kind != "chain":
                         if st["min_slack"] is None or slack < st["min_slack"]:

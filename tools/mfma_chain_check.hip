@@ -23,18 +23,22 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 
-enum { V_BUILTIN = 0, V_ASM0, V_ASM3, V_ASM7, V_ASM15, V_ASM_NOREAD, V_K32K32, V_ASM4, V_ASM5, V_ASM6, V_K16K32_BUILTIN, V_K16K32_ASM0, V_F16_MX_ASM0, V_MX_F16_ASM0, V_F16_MX_ASM7, NVAR };
+enum { V_BUILTIN = 0, V_ASM0, V_ASM3, V_ASM7, V_ASM15, V_ASM_NOREAD, V_K32K32, V_ASM4, V_ASM5, V_ASM6, V_K16K32_BUILTIN, V_K16K32_ASM0, V_F16_MX_ASM0, V_MX_F16_ASM0, V_F16_MX_ASM7, V_F16_MXB8_ASM0, V_MXB8_F16_ASM0, V_MX4_MXB8_ASM0, V_MXB8_MX4_ASM0, NVAR };
 static const char* VNAME[NVAR] = {"builtin K32->K16", "asm K32->K16, 0 states between", "asm, s_nop 3 between", "asm, s_nop 7 between", "asm, s_nop 15 between",
                                   "asm, VALU read after 2 states (positive control)", "builtin K32->K32 (shipped form)",
                                   "asm, s_nop 4 between (5 states)", "asm, s_nop 5 between (6 states)", "asm, s_nop 6 between (7 states)",
                                   "builtin K16->K32 (reverse order)", "asm K16->K32, 0 states between",
                                   "asm f16 K32 -> fp4 scale MFMA, 0 states (the MX kernels' pass 0 -> pass 1)", "asm fp4 scale MFMA -> f16 K32, 0 states",
-                                  "asm f16 K32 -> fp4 scale MFMA, s_nop 7 between"};
+                                  "asm f16 K32 -> fp4 scale MFMA, s_nop 7 between",
+                                  "asm f16 K32 -> fp4 x bf8 scale MFMA (cbsz:4 blgp:1), 0 states (round 6: E5M2 activations)", "asm fp4 x bf8 scale MFMA -> f16 K32, 0 states",
+                                  "asm fp4 x fp4 scale MFMA -> fp4 x bf8 scale MFMA, 0 states", "asm fp4 x bf8 scale MFMA -> fp4 x fp4 scale MFMA, 0 states"};
 
 template <int VAR>
 __global__ __launch_bounds__(256, 4) void chain_kernel(const h8* __restrict__ A, const h8* __restrict__ B, const h4* __restrict__ A2, const h4* __restrict__ B2,
-                                                       f4* __restrict__ out, int iters, int nsets, const u32x4* __restrict__ QA, const u32x4* __restrict__ QB) {
+                                                       f4* __restrict__ out, int iters, int nsets, const u32x4* __restrict__ QA, const u32x4* __restrict__ QB,
+                                                       const u32x8* __restrict__ QB8) {
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     f4 sum = f4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
@@ -69,6 +73,27 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(const h8* __restrict__ A,
                 asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %3, %4, %0, %5, %5 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
                              : "+v"(acc) : "v"(a), "v"(b), "v"(qa), "v"(qb), "v"(one));
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc));
+        } else if constexpr (VAR == V_F16_MXB8_ASM0 || VAR == V_MXB8_F16_ASM0 || VAR == V_MX4_MXB8_ASM0 || VAR == V_MXB8_MX4_ASM0) {
+            // (round 6) the B operand of the block-scaled MFMA as E5M2: 32 bytes per lane (byte k = element k of the lane's K block), the same integers as QB
+            const u32x4 qa = QA[set * 64 + lane], qb = QB[set * 64 + lane];
+            const u32x8 qb8 = QB8[set * 64 + lane];          // (8-bit layout: lane group j = elements 16 j .. + 15 in registers 0-3, 64 + 16 j .. in 4-7)
+            const int one = 127;
+            asm volatile("s_nop 1" ::: "memory");
+            if constexpr (VAR == V_F16_MXB8_ASM0)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %3, %4, %0, %5, %5 op_sel_hi:[0,0,0] cbsz:4 blgp:1"
+                             : "+v"(acc) : "v"(a), "v"(b), "v"(qa), "v"(qb8), "v"(one));
+            else if constexpr (VAR == V_MXB8_F16_ASM0)
+                asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %3, %4, %0, %5, %5 op_sel_hi:[0,0,0] cbsz:4 blgp:1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                             : "+v"(acc) : "v"(a), "v"(b), "v"(qa), "v"(qb8), "v"(one));
+            else if constexpr (VAR == V_MX4_MXB8_ASM0)
+                asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %4, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\t"
+                             "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %3, %0, %4, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:1"
+                             : "+v"(acc) : "v"(qa), "v"(qb), "v"(qb8), "v"(one));
+            else
+                asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %3, %0, %4, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:1\n\t"
+                             "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %4, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                             : "+v"(acc) : "v"(qa), "v"(qb), "v"(qb8), "v"(one));
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc));
         } else {
             // operands are settled (loaded, waited for by the compiler, then two states of distance) before the string starts
             asm volatile("s_nop 1" ::: "memory");
@@ -102,7 +127,9 @@ int main() {
     const int nsets = 64, blocks = 1024 * 4, iters = 400;
     std::vector<_Float16> A(nsets * 64 * 8), B(nsets * 64 * 8), A2(nsets * 64 * 4), B2(nsets * 64 * 4);
     std::vector<float> exp_set((size_t)nsets * 64 * 4), exp_mx((size_t)nsets * 64 * 4);
-    std::vector<unsigned> QA((size_t)nsets * 64 * 4, 0u), QB((size_t)nsets * 64 * 4, 0u);
+    std::vector<unsigned> QA((size_t)nsets * 64 * 4, 0u), QB((size_t)nsets * 64 * 4, 0u), QB8((size_t)nsets * 64 * 8, 0u);
+    std::vector<float> exp_mx2((size_t)nsets * 64 * 4);
+    auto bf8 = [](int v) { const unsigned mag[4] = {0x00u, 0x3Cu, 0x40u, 0x42u}; return (v < 0 ? 0x80u : 0u) | mag[v < 0 ? -v : v]; };      // E5M2 codes of 0, 1, 2, 3
     auto fp4 = [](int v) { const unsigned mag[4] = {0u, 2u, 4u, 5u}; return (v < 0 ? 8u : 0u) | mag[v < 0 ? -v : v]; };
     unsigned rng = 12345u;
     auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 24) % 7) - 3; };
@@ -116,6 +143,7 @@ int main() {
             for (int e = 0; e < 32; ++e) {
                 QA[((size_t)s * 64 + l) * 4 + e / 8] |= fp4(qa[l & 15][32 * (l >> 4) + e]) << (4 * (e % 8));
                 QB[((size_t)s * 64 + l) * 4 + e / 8] |= fp4(qb[32 * (l >> 4) + e][l & 15]) << (4 * (e % 8));
+                QB8[((size_t)s * 64 + l) * 8 + e / 4] |= bf8(qb[(e < 16 ? 16 * (l >> 4) + e : 64 + 16 * (l >> 4) + e - 16)][l & 15]) << (8 * (e % 4));
             }
         for (int l = 0; l < 64; ++l) {
             for (int e = 0; e < 8; ++e) { A[(s * 64 + l) * 8 + e] = (_Float16)a[l & 15][8 * (l >> 4) + e]; B[(s * 64 + l) * 8 + e] = (_Float16)b[8 * (l >> 4) + e][l & 15]; }
@@ -130,23 +158,27 @@ int main() {
                 for (int k = 0; k < 32; ++k) w += a[r][k] * b[k][c];
                 for (int k = 0; k < 128; ++k) w += qa[r][k] * qb[k][c];
                 exp_mx[((size_t)s * 64 + l) * 4 + i] = (float)w;
+                int w2 = 0;
+                for (int k = 0; k < 128; ++k) w2 += 2 * qa[r][k] * qb[k][c];
+                exp_mx2[((size_t)s * 64 + l) * 4 + i] = (float)w2;
             }
         }
     }
     h8 *dA, *dB; h4 *dA2, *dB2; f4* dout;
     CHK(hipMalloc(&dA, A.size() * 2)); CHK(hipMalloc(&dB, B.size() * 2)); CHK(hipMalloc(&dA2, A2.size() * 2)); CHK(hipMalloc(&dB2, B2.size() * 2));
-    u32x4 *dQA, *dQB;
-    CHK(hipMalloc(&dQA, QA.size() * 4)); CHK(hipMalloc(&dQB, QB.size() * 4));
+    u32x4 *dQA, *dQB; u32x8* dQB8;
+    CHK(hipMalloc(&dQA, QA.size() * 4)); CHK(hipMalloc(&dQB, QB.size() * 4)); CHK(hipMalloc(&dQB8, QB8.size() * 4));
+    CHK(hipMemcpy(dQB8, QB8.data(), QB8.size() * 4, hipMemcpyHostToDevice));
     CHK(hipMemcpy(dQA, QA.data(), QA.size() * 4, hipMemcpyHostToDevice)); CHK(hipMemcpy(dQB, QB.data(), QB.size() * 4, hipMemcpyHostToDevice));
     const size_t nout = (size_t)blocks * 4 * 64;
     CHK(hipMalloc(&dout, nout * sizeof(f4)));
     CHK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice)); CHK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
     CHK(hipMemcpy(dA2, A2.data(), A2.size() * 2, hipMemcpyHostToDevice)); CHK(hipMemcpy(dB2, B2.data(), B2.size() * 2, hipMemcpyHostToDevice));
     // expectation per (wave, lane, i): sum over it of exp_set[(gw + it) % nsets] * (1 + (it & 3)): small integers, exact in fp32 (|.| < 2^24)
-    std::vector<float> expect(nout * 4), expect_mx(nout * 4), got(nout * 4);
-    for (int tab = 0; tab < 2; ++tab) {
-        std::vector<float>& ex = tab ? expect_mx : expect;
-        const std::vector<float>& es = tab ? exp_mx : exp_set;
+    std::vector<float> expect(nout * 4), expect_mx(nout * 4), expect_mx2(nout * 4), got(nout * 4);
+    for (int tab = 0; tab < 3; ++tab) {
+        std::vector<float>& ex = tab == 2 ? expect_mx2 : tab ? expect_mx : expect;
+        const std::vector<float>& es = tab == 2 ? exp_mx2 : tab ? exp_mx : exp_set;
         for (size_t gw = 0; gw < (size_t)blocks * 4; ++gw) {
             if (gw >= (size_t)nsets) {          // the operand sequence of a wave depends on gw % nsets only
                 memcpy(&ex[gw * 256], &ex[(gw % nsets) * 256], 256 * sizeof(float));
@@ -166,15 +198,17 @@ int main() {
         for (int rep = 0; rep < 5; ++rep) {
             CHK(hipMemset(dout, 0, nout * sizeof(f4)));
             switch (var) {
-#define LAUNCH(V) case V: hipLaunchKernelGGL(chain_kernel<V>, dim3(blocks), dim3(256), 0, 0, dA, dB, dA2, dB2, dout, iters, nsets, dQA, dQB); break;
+#define LAUNCH(V) case V: hipLaunchKernelGGL(chain_kernel<V>, dim3(blocks), dim3(256), 0, 0, dA, dB, dA2, dB2, dout, iters, nsets, dQA, dQB, dQB8); break;
                 LAUNCH(V_BUILTIN) LAUNCH(V_ASM0) LAUNCH(V_ASM3) LAUNCH(V_ASM7) LAUNCH(V_ASM15) LAUNCH(V_ASM_NOREAD) LAUNCH(V_K32K32) LAUNCH(V_ASM4) LAUNCH(V_ASM5) LAUNCH(V_ASM6) LAUNCH(V_K16K32_BUILTIN) LAUNCH(V_K16K32_ASM0)
                 LAUNCH(V_F16_MX_ASM0) LAUNCH(V_MX_F16_ASM0) LAUNCH(V_F16_MX_ASM7)
+                LAUNCH(V_F16_MXB8_ASM0) LAUNCH(V_MXB8_F16_ASM0) LAUNCH(V_MX4_MXB8_ASM0) LAUNCH(V_MXB8_MX4_ASM0)
 #undef LAUNCH
             }
             CHK(hipDeviceSynchronize());
             CHK(hipMemcpy(got.data(), dout, nout * sizeof(f4), hipMemcpyDeviceToHost));
             long b = 0;
-            const std::vector<float>& ex = (var == V_F16_MX_ASM0 || var == V_MX_F16_ASM0 || var == V_F16_MX_ASM7) ? expect_mx : expect;
+            const std::vector<float>& ex = (var == V_MX4_MXB8_ASM0 || var == V_MXB8_MX4_ASM0) ? expect_mx2 :
+                                           (var == V_F16_MX_ASM0 || var == V_MX_F16_ASM0 || var == V_F16_MX_ASM7 || var == V_F16_MXB8_ASM0 || var == V_MXB8_F16_ASM0) ? expect_mx : expect;
             for (size_t i = 0; i < got.size(); ++i) b += got[i] != ex[i];
             bad += b; runs_bad += b != 0;
         }

@@ -38,10 +38,12 @@ __device__ __forceinline__ i8v rand_i8(uint32_t& s, bool zero, uint32_t mask) {
 // MODE 1:  4 x (32x32x16 f16) per step            (same FLOPs as mode 0: 64x64x32 per wave and step)
 // MODE 2: per 4 steps (K = 128): 64 f16 16x16x32 + 32 MX (2 cross terms x 16 tiles), MX format = FMT
 // MODE 3: MX only: 16 x (16x16x128) per step
-template <int MODE, int FMT>
+// (round 6) FA / FB: the formats of the A and of the B operand (0 = fp8 e4m3, 1 = bf8 e5m2, 2 = fp6, 4 = fp4); FA = 4, FB = 1 is the "fp4 weights x E5M2
+// activations" cross term of the maxima-free quantiser: the instruction then runs at the wider operand's rate
+template <int MODE, int FA, int FB>
 __global__ __launch_bounds__(256, 2) void ubench(float* out, long long* ticks, int iters, int zero) {
     uint32_t s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
-    const uint32_t mask = FMT == 0 ? 0x7e7e7e7eu | 0x80808080u : 0xffffffffu;   // fp8: no NaN codes
+    const uint32_t mask = (FA == 0 || FB == 0) ? 0x7e7e7e7eu | 0x80808080u : (FA == 1 || FB == 1) ? 0x7b7b7b7bu | 0x80808080u : 0xffffffffu;   // fp8 / bf8: no NaN / inf codes
     h8 a[4], b[4];
     i8v ma[4], mb[4], na[4], nb[4];
     for (int i = 0; i < 4; ++i) {
@@ -82,9 +84,9 @@ __global__ __launch_bounds__(256, 2) void ubench(float* out, long long* ticks, i
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i * 4 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ma[i], mb[j], acc[i * 4 + j], FMT, FMT, 0, sc, 0, sc);
+                    acc[i * 4 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ma[i], mb[j], acc[i * 4 + j], FA, FB, 0, sc, 0, sc);
                     if (MODE == 2)
-                        acc[i * 4 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(na[i], nb[j], acc[i * 4 + j], FMT, FMT, 0, sc, 0, sc);
+                        acc[i * 4 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(na[i], nb[j], acc[i * 4 + j], FA, FB, 0, sc, 0, sc);
                 }
         }
     }
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void ubench(float* out, long long* ticks, i
 
 struct Result { double ms, tflops_f16, tflops_mx, ghz; };
 
-template <int MODE, int FMT>
+template <int MODE, int FA, int FB = FA>
 static Result run(const char* name, int iters, int zero, float* d_out, long long* d_ticks) {
     const int blocks = 256 * 2 * 4;     // 2 blocks of 4 waves per CU resident, 4 rounds
     hipEvent_t e0, e1;
@@ -106,7 +108,7 @@ static Result run(const char* name, int iters, int zero, float* d_out, long long
     Result best{1e30, 0, 0, 0};
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((ubench<MODE, FMT>), dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, iters, zero);
+        hipLaunchKernelGGL((ubench<MODE, FA, FB>), dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, iters, zero);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -135,42 +137,56 @@ static float fp8_val(int c) {   // OCP e4m3fn
     return s ? -v : v;
 }
 
-template <int FMT>
+static float bf8_val(int c) {   // OCP e5m2 (the top byte of an IEEE half)
+    int s = c >> 7, e = (c >> 2) & 31, m = c & 3;
+    float v = e == 0 ? ldexpf((float)m / 4.f, -14) : ldexpf(1.f + m / 4.f, e - 15);
+    return s ? -v : v;
+}
+
+template <int FA, int FB>
 __global__ void mx_one(const int* a, const int* b, const int* sa, const int* sb, float* d) {
     int l = threadIdx.x;
     i8v va, vb;
     for (int i = 0; i < 8; ++i) { va[i] = a[l * 8 + i]; vb[i] = b[l * 8 + i]; }
     f4 c{0, 0, 0, 0};
-    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, vb, c, FMT, FMT, 0, sa[l], 0, sb[l]);
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, vb, c, FA, FB, 0, sa[l], 0, sb[l]);
     for (int r = 0; r < 4; ++r) d[l * 4 + r] = c[r];
 }
 
-template <int FMT>
+template <int FA, int FB = FA>
 static void layout_check() {
     std::vector<int> a(64 * 8, 0), b(64 * 8, 0), sa(64), sb(64);
-    srand(7 + FMT);
-    const int bytes = FMT == 4 ? 16 : 32;
+    srand(7 + FA + 16 * FB);
+    auto fix = [](int c, int f) {           // no NaN / inf codes; bf8 additionally inside a range whose products stay well inside fp32 (exponent field 8..22)
+        if (f == 0 && (c & 0x7f) == 0x7f) c ^= 1;
+        if (f == 1) c = (c & 0x83) | ((8 + ((c >> 2) & 31) % 15) << 2);
+        return c;
+    };
     for (int l = 0; l < 64; ++l) {
-        for (int i = 0; i < bytes; ++i) {
-            int ca = rand() & 255, cb = rand() & 255;
-            if (FMT == 0) { if ((ca & 0x7f) == 0x7f) ca ^= 1; if ((cb & 0x7f) == 0x7f) cb ^= 1; }
-            ((unsigned char*)&a[l * 8])[i] = ca; ((unsigned char*)&b[l * 8])[i] = cb;
-        }
+        for (int i = 0; i < (FA == 4 ? 16 : 32); ++i) ((unsigned char*)&a[l * 8])[i] = fix(rand() & 255, FA);
+        for (int i = 0; i < (FB == 4 ? 16 : 32); ++i) ((unsigned char*)&b[l * 8])[i] = fix(rand() & 255, FB);
         sa[l] = 125 + rand() % 5; sb[l] = 125 + rand() % 5;    // byte 0 of the scale register (opsel 0)
     }
-    // assumed layout: lane l holds row (A) / column (B) l % 16, K block l / 16 (32 consecutive k); fp4: byte j = k 2j (low nibble), 2j+1
-    auto elem = [&](const std::vector<int>& v, int l, int k) {
-        const unsigned char* p = (const unsigned char*)&v[l * 8];
-        if (FMT == 4) { int byte = p[k >> 1]; return fp4_val((k & 1) ? byte >> 4 : byte & 15); }
-        return fp8_val(p[k]);
+    // layout (tools/mx_layout_probe.hip, round 6): lane l holds row (A) / column (B) l % 16.  fp4: K block l / 16 = 32 consecutive elements, byte j = elements 2j (low
+    // nibble), 2j + 1, in the FIRST four registers of the operand.  8-bit formats: lane group j = l / 16 holds elements 16 j .. 16 j + 15 in registers 0-3 and
+    // 64 + 16 j .. 64 + 16 j + 15 in registers 4-7 -- also when the other operand is fp4.  The E8M0 scale of K block kb (elements 32 kb .. 32 kb + 31) of row m is
+    // byte 0 of lane m + 16 kb's scale register in EVERY format.
+    auto elem = [&](const std::vector<int>& v, int m, int k, int f) {      // element k (0..127) of row / column m
+        if (f == 4) {
+            const unsigned char* p = (const unsigned char*)&v[(m + 16 * (k >> 5)) * 8];
+            int byte = p[(k & 31) >> 1];
+            return fp4_val((k & 1) ? byte >> 4 : byte & 15);
+        }
+        const unsigned char* p = (const unsigned char*)&v[(m + 16 * ((k & 63) >> 4)) * 8];
+        const int c = p[(k & 15) + 16 * (k >> 6)];
+        return f == 1 ? bf8_val(c) : fp8_val(c);
     };
     double ref[16][16];
     for (int m = 0; m < 16; ++m) for (int n = 0; n < 16; ++n) {
         double acc = 0;
-        for (int kb = 0; kb < 4; ++kb) {
-            int la = kb * 16 + m, lb = kb * 16 + n;
-            double sc = ldexp(1.0, sa[la] - 127) * ldexp(1.0, sb[lb] - 127);
-            for (int k = 0; k < 32; ++k) acc += sc * elem(a, la, k) * elem(b, lb, k);
+        for (int k = 0; k < 128; ++k) {
+            const int kb = k >> 5;
+            acc += ldexp(1.0, sa[kb * 16 + m] - 127) * ldexp(1.0, sb[kb * 16 + n] - 127) * elem(a, m, k, FA) * elem(b, n, k, FB);
         }
         ref[m][n] = acc;
     }
@@ -178,7 +194,7 @@ static void layout_check() {
     CK(hipMalloc(&da, 64 * 32)); CK(hipMalloc(&db, 64 * 32)); CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256)); CK(hipMalloc(&dd, 1024));
     CK(hipMemcpy(da, a.data(), 64 * 32, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), 64 * 32, hipMemcpyHostToDevice));
     CK(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL((mx_one<FMT>), dim3(1), dim3(64), 0, 0, da, db, dsa, dsb, dd);
+    hipLaunchKernelGGL((mx_one<FA, FB>), dim3(1), dim3(64), 0, 0, da, db, dsa, dsb, dd);
     std::vector<float> d(256);
     CK(hipMemcpy(d.data(), dd, 1024, hipMemcpyDeviceToHost));
     double maxerr = 0, maxref = 0;
@@ -187,7 +203,8 @@ static void layout_check() {
         maxerr = fmax(maxerr, fabs(d[l * 4 + r] - ref[row][col]));
         maxref = fmax(maxref, fabs(ref[row][col]));
     }
-    printf("MX layout check fmt %d: max |gpu - host| = %.3e (max |ref| %.3e) -> %s\n", FMT, maxerr, maxref, maxerr <= 1e-5 * maxref ? "OK" : "MISMATCH");
+    printf("MX layout check A fmt %d x B fmt %d: max |gpu - host| = %.3e (max |ref| %.3e) -> %s\n", FA, FB, maxerr, maxref,
+           maxerr <= 1e-5 * maxref ? "OK" : maxerr <= 2e-4 * maxref ? "OK (layout; the 8-bit formats' adder tree keeps ~14 bits below the largest product of a 128-element dot: a wrong layout is O(1))" : "MISMATCH");
 }
 
 int main(int argc, char** argv) {
@@ -196,6 +213,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_out, 256 * 2 * 4 * 256 * 4)); CK(hipMalloc(&d_ticks, 8));
     layout_check<4>();
     layout_check<0>();
+    layout_check<1>();
+    layout_check<4, 1>();          // fp4 weights x E5M2 activations (round 6)
+    layout_check<1, 4>();
     for (int zero = 0; zero < 2; ++zero) {
         printf("== operands %s, %d iterations, 2 x 4 waves per CU\n", zero ? "ZERO" : "random", iters);
         run<0, 0>("16 x f16 16x16x32 per step (phased kernel mix)", iters, zero, d_out, d_ticks);
@@ -203,6 +223,9 @@ int main(int argc, char** argv) {
         run<3, 0>("16 x MX fp8 16x16x128", iters / 4, zero, d_out, d_ticks);
         run<3, 2>("16 x MX fp6 16x16x128", iters / 4, zero, d_out, d_ticks);
         run<3, 4>("16 x MX fp4 16x16x128", iters / 4, zero, d_out, d_ticks);
+        run<3, 1>("16 x MX bf8 16x16x128", iters / 4, zero, d_out, d_ticks);
+        run<3, 4, 1>("16 x MX fp4 (A) x bf8 (B) 16x16x128", iters / 4, zero, d_out, d_ticks);
+        run<2, 4, 1>("K=128: 64 f16 + 32 MX fp4 x bf8 (2.0 units)", iters / 4, zero, d_out, d_ticks);
         run<2, 0>("K=128: 64 f16 + 32 MX fp8 (2.0 units)", iters / 4, zero, d_out, d_ticks);
         run<2, 2>("K=128: 64 f16 + 32 MX fp6 (1.5 units)", iters / 4, zero, d_out, d_ticks);
         run<2, 4>("K=128: 64 f16 + 32 MX fp4 (1.5 units)", iters / 4, zero, d_out, d_ticks);

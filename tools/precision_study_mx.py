@@ -25,7 +25,23 @@ FORMATS = {            # ebits, mbits, emax (unbiased exponent of the largest bi
     "fp4": (2, 1, 2, 6.0),
     "fp6": (2, 3, 2, 7.5),
     "fp8": (4, 3, 8, 448.0),
+    "bf8": (5, 2, 15, 57344.0),      # OCP E5M2 = the top byte of an IEEE half
 }
+
+
+def e5m2_hi(xh, rne):
+    """Round 6 study: E5M2 code of an fp16 value WITHOUT a block scale -- the top byte of the half (truncation: one v_perm_b32 per four values), or
+    round-to-nearest-even on the dropped byte (one packed 16-bit add per two values in front of it)."""
+    bits = xh.half().numpy().view(np.uint16).astype(np.uint32)
+    if rne:
+        bits = bits + 0x7F + ((bits >> 8) & 1)          # no carry out of the exponent field for the activations at hand (|x| << 57344)
+    return torch.from_numpy((bits & 0xFF00).astype(np.uint16).view(np.float16).astype(np.float32)).reshape(xh.shape)
+
+
+def e5m2_lo(xl):
+    """the remainder x - fp16(x) in E5M2 with ONE constant E8M0 scale 2^-11 for every block (|xl| <= 2^-11 2^e: xl 2^11 is inside E5M2's normal range
+    for every fp16-normal x): v_cvt_scalef32_pk_bf8_f32, round-to-nearest-even, saturating; no block maximum."""
+    return quant_elem(xl * 2048.0, "bf8") / 2048.0
 
 
 def r16(x):
@@ -81,7 +97,11 @@ LO_FIXED = [False]          # set per recipe by emulate()
 
 class Recipe:
     def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None, mrf16=False,
-                 engine_flow=False, mrf_planes=None, lo_fixed=False):
+                 engine_flow=False, mrf_planes=None, lo_fixed=False, e5m2_stages=(), e5m2_rne=False):
+        # e5m2_stages: generator stages (0-3; conv_pre / the up-conv INTO stage i count as stage i's input) whose ACTIVATION cross-term operands are E5M2
+        # without block maxima (weights stay block-scaled fp4): Q(xh) = top byte of the fp16 hi plane, Q(xl) = E5M2 of xl 2^11 at the constant scale 2^-11;
+        # a residual rebuilt from planes in such a stage uses hi + that E5M2 remainder
+        self.e5m2_stages, self.e5m2_rne = tuple(e5m2_stages), e5m2_rne
         self.lo_fixed = lo_fixed          # activation remainders (operand planes and residual planes) with the derived scale
         self.name, self.cross, self.res32, self.op32, self.lo_terms = name, cross, res32, op32, lo_terms
         # mrf16: the first two scaled ResBlock outputs of a stage are stored in fp16 and added in the third one's fp32 epilogue (the fast mode's MRF sum:
@@ -100,12 +120,12 @@ def planes_roundtrip(x, fmt):
     a = F.leaky_relu(x, 0.1)
     h = r16(a)
     lo = a - h
-    lo = r16(lo) if fmt == "f16" else (mx_quant_lo_fixed(lo, h, fmt, 1) if LO_FIXED[0] else mx_quant(lo, fmt, 1))
+    lo = e5m2_lo(lo) if fmt == "e5m2" else r16(lo) if fmt == "f16" else (mx_quant_lo_fixed(lo, h, fmt, 1) if LO_FIXED[0] else mx_quant(lo, fmt, 1))
     a2 = h + lo
     return torch.where(a2 >= 0, a2, a2 * 10.0)
 
 
-def conv_mx(x, w, b, rc, transposed=False, **kw):
+def conv_mx(x, w, b, rc, transposed=False, e5m2=False, **kw):
     """x [1, C, T] fp32, w fp32.  hi.hi in fp16 operands + cross terms in rc.cross (None = omitted, 'f16' = fp16 exact)."""
     op = F.conv_transpose1d if transposed else F.conv1d
     xh, wh = r16(x), r16(w)
@@ -118,6 +138,8 @@ def conv_mx(x, w, b, rc, transposed=False, **kw):
         qa = qb = lambda t, d: r16(t)
     else:
         qa = qb = lambda t, d: mx_quant(t, rc.cross, d)
+    if e5m2:
+        return y + op(e5m2_hi(xh, rc.e5m2_rne), qb(wl, kdim_w), None, **kw) + op(e5m2_lo(xl), qb(wh, kdim_w), None, **kw)
     if "xh_wl" in rc.lo_terms:
         y = y + op(qa(xh, 1), qb(wl, kdim_w), None, **kw)
     if "xl_wh" in rc.lo_terms:
@@ -133,18 +155,24 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
         st = lambda t: planes_roundtrip(t, rc.res_planes)
     so = (lambda t: t) if rc.op32 else r16               # conv1 -> conv2 intermediates (operand-only tensors)
 
+    stage = [0]
+
     def conv(x, name, **kw):
-        return conv_mx(x, fold_weight_norm(sd, name), sd[name + ".bias"], rc, **kw)
+        return conv_mx(x, fold_weight_norm(sd, name), sd[name + ".bias"], rc, e5m2=stage[0] in rc.e5m2_stages, **kw)
 
     x = mel_ct.unsqueeze(0)
     x = st(conv(x, prefix + ".conv_pre", padding=3))
     nk = len(shapes.rb_kernels)
-    st_planes = st
     for i, (u, k) in enumerate(zip(shapes.up_rates, shapes.up_kernels)):
-        if rc.engine_flow and rc.res_planes:
-            st = st_planes if i + 1 < len(shapes.up_rates) else (lambda t: t)
+        stage[0] = i
+        if rc.res_planes:
+            fmt_i = "e5m2" if i in rc.e5m2_stages else rc.res_planes
+            st = (lambda t, f=fmt_i: planes_roundtrip(t, f))
+            if rc.engine_flow and i + 1 == len(shapes.up_rates):
+                st = (lambda t: t)
         x = F.leaky_relu(x, 0.1)
-        x = conv_mx(x, fold_weight_norm(sd, f"{prefix}.ups.{i}"), sd[f"{prefix}.ups.{i}.bias"], rc, transposed=True,
+        # the up-conv INTO stage i reads stage i - 1's output planes
+        x = conv_mx(x, fold_weight_norm(sd, f"{prefix}.ups.{i}"), sd[f"{prefix}.ups.{i}.bias"], rc, transposed=True, e5m2=max(i - 1, 0) in rc.e5m2_stages,
                     stride=u, padding=(k - u) // 2)
         x = st(x)
         xs = None
@@ -219,6 +247,12 @@ def main():
             Recipe("ENGINE r4 + MRF partials as hi + fp4 remainder", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4"),
             Recipe("ENGINE r4 + MRF partials as hi + fp4 remainder, stage 3 from planes too", "fp4", res_planes="fp4", mrf_planes="fp4"),
             Recipe("ENGINE r4 + MRF partials, remainder scale DERIVED from the hi scale (bl = bh - 11)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", lo_fixed=True),
+            Recipe("E5M2 r6: ENGINE r4 + MRF partials, stage 3 activations E5M2 (truncated hi byte)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(3,)),
+            Recipe("E5M2 r6: same, hi byte rounded to nearest", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(3,), e5m2_rne=True),
+            Recipe("E5M2 r6: stages 2 + 3 (truncated)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(2, 3)),
+            Recipe("E5M2 r6: stages 2 + 3 (nearest)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(2, 3), e5m2_rne=True),
+            Recipe("E5M2 r6: every stage (truncated)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(0, 1, 2, 3)),
+            Recipe("E5M2 r6: every stage (nearest)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(0, 1, 2, 3), e5m2_rne=True),
             Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
             Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
         ]
