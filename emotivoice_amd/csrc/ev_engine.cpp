@@ -789,6 +789,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     memset(&rp, 0, sizeof rp);
                     rp.x = p.res; rp.ldx = cout; rp.w1 = w1; rp.b1 = b1; rp.w2 = p.W; rp.w1_mx = w1m; rp.w2_mx = w2m;
                     rp.M = p.M; rp.k = k; rp.dil = dil; rp.gmin = 0; rp.gmax = rows_out; rp.epi = p;
+                    if (c.mx_act_format != 0) rp.epi.reserved0 |= 16;          // block-scaled fp4 activation operands (rounds 3-5) instead of E5M2
                     const double fl = 2.0 * 2.0 * valid_out * cout * (double)cout * k;
                     ConvGemmParams shape = p; shape.dil = dil;
                     KScope ks(h, "voc_resblock_pair_c32_mx", fl, valid_out * cout * 4.0 * 2.0, sj, &shape);
@@ -1003,8 +1004,8 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
         return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
     if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3 && cfg->vocoder_precision != EV_PREC_MX)
         return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16, EV_PREC_X3 or EV_PREC_MX");
-    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs | cfg->mx_mrf | cfg->decoder_ln_planes | cfg->token_splitk) & ~1)
-        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs / mx_mrf / decoder_ln_planes / token_splitk must be 0 or 1");
+    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs | cfg->mx_mrf | cfg->decoder_ln_planes | cfg->token_splitk | cfg->mx_act_format) & ~1)
+        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs / mx_mrf / decoder_ln_planes / token_splitk / mx_act_format must be 0 or 1");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));

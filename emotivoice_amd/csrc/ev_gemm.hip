@@ -2539,6 +2539,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_kernel(const ResPair
 #include "ev_gemm_mx.h"
 #include "ev_gemm_mx64.h"
 #include "ev_pair_mx.h"
+#include "ev_pair_e5.h"
 
 #include "ev_conv64_mx.h"
 #include "ev_pair64_mx.h"
@@ -2564,6 +2565,7 @@ int init_device_kernels(int device) {
     if (mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (mx64_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (pair_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
+    if (pair_e5_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (conv64_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     if (pair64_mx_set_attributes() != hipSuccess) e = hipErrorInvalidValue;
     g_dev_ready[device] = (e == hipSuccess);
@@ -2575,6 +2577,25 @@ int launch_resblock_pair_c32_mx(const ResPairParams& p, hipStream_t s) {
         (p.k - 1) / 2 * (p.dil + 1) * 2 + 256 > 320 || p.ldx != 32) return -1;
     const int n_cu = device_cus();
     const int h2 = (p.k - 1) / 2;
+    // (round 6) E5M2 activation operands in the cross terms, no block maxima (ev_pair_e5.h), where they pay: k = 3, the pairs whose time is the quantisers' and the
+    // tile's fixed cost (-8 ... -12 % per launch, -4 % with the accumulate-in; more accurate than fp4 on every shape).  At k = 7 / 11 the same kernel measures +0 ... +5 %:
+    // those launches are bound by their conv phases (one LDS fragment read per MFMA), and the bf8 operand doubles the B-fragment bytes and runs the block-scaled MFMA
+    // at the fp8 rate (profiles/r6_b_pair_e5_ab.txt) -- they keep the fp4 kernel.  The rule is on the layer's shape only, for EVERY M: an utterance gets the same
+    // bits alone and in a batch.  epi.reserved0 bit 4 (16): fp4 everywhere (ev_config.mx_act_format = 1); bit 5 (32): E5M2 at every k (tools/bench_pair_mx.py).
+    if (!(e.reserved0 & 16) && (p.k == 3 || (e.reserved0 & 32))) {
+        const int bmo2 = 128 - 2 * h2, ntiles2 = (p.M + bmo2 - 1) / bmo2;
+        const int grid2 = (ntiles2 + 1) / 2 < n_cu ? (ntiles2 + 1) / 2 : n_cu;
+#define EV_PE5_LAUNCH(KK)                                                                                                           \
+        if (e.acc32) hipLaunchKernelGGL((resblock_pair_c32_e5_kernel<KK, 1>), dim3(grid2), dim3(512), PairE5Geom<KK>::TOTAL, s, p);   \
+        else hipLaunchKernelGGL((resblock_pair_c32_e5_kernel<KK, 0>), dim3(grid2), dim3(512), PairE5Geom<KK>::TOTAL, s, p);
+        switch (p.k) {
+            case 3: EV_PE5_LAUNCH(3) break;
+            case 7: EV_PE5_LAUNCH(7) break;
+            default: EV_PE5_LAUNCH(11) break;
+        }
+#undef EV_PE5_LAUNCH
+        return 0;
+    }
     // two-group schedule (resblock_pair_c32_mx2_kernel: 128-row tiles, one per 4-wave group) once there are enough tiles to keep every group of every
     // CU busy; epi.reserved0 bit 2: in-process A/B (lock-step kernel).  Which kernel a launch takes depends on M, the result does not (bit-identical).
     {

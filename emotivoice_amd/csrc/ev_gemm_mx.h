@@ -111,6 +111,11 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wt = wave & 3, wc = wave >> 2;          // wc is also the phase group: waves w and w + 4 share a SIMD
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // EV_MXT (tuning builds: build.py --variant mxt EV_MXT; tools/bench_mxgemm.py --timeline): wave 0 of every block records the chip-wide 100-MHz clock
+    // (s_memrealtime) at its start, at the start of its epilogue and at its end, + its hardware id, to ((unsigned long long*)p.row_seq)[blockIdx.x * 4 + 0..3]
+#ifdef EV_MXT
+    const unsigned long long mxt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // (Round 4 tried a persistent tile loop here, twice.  Second form: the next tile's first six requests and its row_valid look-up issued between a tile's last
     // barrier and its epilogue, 16-row swizzled epilogue scratch beside them: bit-identical, 3-5 % SLOWER in every shape, with or without the early requests,
@@ -333,6 +338,9 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
         return;
     }
 #endif
+#ifdef EV_MXT
+    const unsigned long long mxt1 = __builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC);
     else {
         EV_TRACE_EPI_DUMMY
@@ -340,6 +348,20 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
         // in the residual-from-planes variants -- every instantiation compiles without spills (profiles/r4_e_mx_persistent_prefetch_ab.txt, dbg 72)
         gemm_epilogue_fast<MT, NT, EPI, 16>(p, acc, smem + wave * 4096, m0 + wt * 64, n0 + wc * TC EV_TRACE_EPI_ARGS);
     }
+#ifdef EV_MXT
+    if (p.row_seq && wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the wave's own stores have left for L2)
+        const unsigned long long mxt2 = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(p.row_seq)) + (size_t)blockIdx.x * 4;
+            o[0] = mxt0; o[1] = mxt1; o[2] = mxt2; o[3] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+#endif
 }
 
 #include "ev_gemm_mx1.h"

@@ -34,7 +34,8 @@ def resolve_precision(precision, decoder_precision, vocoder_precision):
 def make_ev_config(shapes: EVShapes, decoder_precision: str = "mx", keep_stages: bool = False,
                    token_rate: str = "split", vocoder_chunk_mb: int = 0, vocoder_streams: int = 0,
                    vocoder_precision: str = "mx", mx_residual: str = "planes", decoder_attention: str = "split",
-                   fused_pairs: bool = True, mx_mrf: str = "planes", decoder_ln: str = "planes", token_splitk: bool = True) -> _ffi.ev_config:
+                   fused_pairs: bool = True, mx_mrf: str = "planes", decoder_ln: str = "planes", token_splitk: bool = True,
+                   mx_act_format: str = "e5m2") -> _ffi.ev_config:
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
     for f in ("n_vocab", "n_speaker", "n_mels", "hidden", "heads", "enc_layers", "dec_layers", "ffn_kernel", "bert_dim",
@@ -65,6 +66,7 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "mx", keep_stages:
     cfg.mx_mrf = {"planes": 0, "fp32": 1}[mx_mrf]                    # running MRF sum of an MX stage: partial plane sets / an fp32 tensor
     cfg.decoder_ln_planes = {"planes": 0, "fp32": 1}[decoder_ln]     # MX decoder: LayerNorm writes its consumer's plane set / fp32 + a planes pass
     cfg.token_splitk = 0 if token_splitk else 1                       # the token-rate conv-FFN's second conv split-K (shape rule) / one pass
+    cfg.mx_act_format = {"e5m2": 0, "fp4": 1}[mx_act_format]          # activation operand of the cross terms where a kernel offers both (fused C = 32 pairs)
     return cfg
 
 
@@ -75,14 +77,14 @@ class EVEngine:
                  keep_stages: bool = False, token_rate: str = "split", vocoder_chunk_mb: int = 0,
                  vocoder_streams: int = 0, vocoder_precision: Optional[str] = None, precision: Optional[str] = None,
                  mx_residual: str = "planes", decoder_attention: str = "split", fused_pairs: bool = True, mx_mrf: str = "planes",
-                 decoder_ln: str = "planes", token_splitk: bool = True):
+                 decoder_ln: str = "planes", token_splitk: bool = True, mx_act_format: str = "e5m2"):
         self.shapes = shapes or EVShapes()
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
         decoder_precision, vocoder_precision = resolve_precision(precision, decoder_precision, vocoder_precision)
         self.decoder_precision, self.vocoder_precision = decoder_precision, vocoder_precision
         cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate, vocoder_chunk_mb, vocoder_streams,
-                             vocoder_precision, mx_residual, decoder_attention, fused_pairs, mx_mrf, decoder_ln, token_splitk)
+                             vocoder_precision, mx_residual, decoder_attention, fused_pairs, mx_mrf, decoder_ln, token_splitk, mx_act_format)
         if self._lib.ev_create(device_id, C.byref(cfg), C.byref(self._h)) != 0:
             raise EVError(self._lib.ev_last_error(None).decode())
         self.device_id = device_id

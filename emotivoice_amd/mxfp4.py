@@ -72,6 +72,38 @@ def split_hi_lo(x: np.ndarray):
     return hi, x - hi
 
 
+# ---- Round 6: maxima-free E5M2 operands for the ACTIVATION side of the cross terms (ev_pair_e5.h).  OCP E5M2 (bf8: s eeeee mm, bias 15) is the top byte of an
+# IEEE half, so Q(xh) needs no conversion, no block maximum and no scale; the remainder x - fp16(x) is at most 2^-11 of x's binade, so xl 2^11 fits E5M2's range
+# for every fp16-normal x and ONE constant E8M0 scale (2^-11) serves every block.
+E5M2_LO_SHIFT = 11
+
+
+def e5m2_decode(codes: np.ndarray) -> np.ndarray:
+    """E5M2 bytes -> fp32 (exact: an E5M2 code is the top byte of the half with a zero low byte)."""
+    return (np.ascontiguousarray(codes, np.uint8).astype(np.uint16) << 8).view(np.float16).astype(np.float32)
+
+
+def e5m2_hi_codes(hi: np.ndarray) -> np.ndarray:
+    """fp16 hi parts (any float dtype holding fp16-representable values) -> their E5M2 codes by TRUNCATION: the top byte of the half (v_perm_b32 on the device)."""
+    return (np.ascontiguousarray(hi).astype(np.float16).view(np.uint16) >> 8).astype(np.uint8)
+
+
+def e5m2_lo_codes(lo: np.ndarray) -> np.ndarray:
+    """fp32 remainders x - fp16(x) -> E5M2 codes of lo 2^11, round to nearest even, saturating (v_cvt_scalef32_pk_bf8_f32 with scale 2^-11)."""
+    y = np.ascontiguousarray(lo, np.float32).astype(np.float64) * float(1 << E5M2_LO_SHIFT)
+    a = np.abs(y)
+    e = np.floor(np.log2(np.maximum(a, 1e-300)))
+    e = np.clip(e, -14, 15)                              # subnormals share the quantum of the smallest normal binade
+    q = np.ldexp(1.0, (e - 2).astype(np.int64))
+    r = np.minimum(np.rint(a / q) * q, 57344.0)          # np.rint: half to even
+    h = np.where(np.signbit(y), -r, r).astype(np.float16)
+    return (h.view(np.uint16) >> 8).astype(np.uint8)
+
+
+def e5m2_lo_decode(codes: np.ndarray) -> np.ndarray:
+    return e5m2_decode(codes) * np.float32(1.0 / (1 << E5M2_LO_SHIFT))
+
+
 W_SCALE_BLOCK = 128     # weights: one scale per (output channel, tap, 128 input channels) = one per MFMA A-row
 
 

@@ -30,11 +30,13 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 5      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info;
+#define EV_ABI_VERSION 6      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info;
                                  3: ev_config.mx_mrf / decoder_ln_planes, partial plane sets in ev_conv_gemm_desc (acc_h ..., mxo_partial);
                                  4: ev_config.token_splitk, ev_conv_gemm_desc.ksplit (same struct sizes);
                                  5: ev_default_config() sets decoder_precision = vocoder_precision = EV_PREC_MX, the mode that meets the 1e-3 contract
-                                    (same struct sizes; until 4 the default was EV_PREC_F16 = 2.4e-3 on zero-mean audio) */
+                                    (same struct sizes; until 4 the default was EV_PREC_F16 = 2.4e-3 on zero-mean audio);
+                                 6: ev_config.mx_act_format (was reserved[0], same struct size): the fused C = 32 pairs of the MX generator default to
+                                    E5M2 activation operands in the cross terms -- the results of the default mode change in their last bits */
 
 typedef struct ev_handle ev_handle;
 
@@ -104,7 +106,10 @@ typedef struct ev_config {
                                    kernel -- because that chain is what a single utterance waits for (B = 1, 64 phonemes: 4.25 -> 3.95 ms; +0.08 ms per
                                    32 x 256-token batch).  Chosen by layer shape only: an utterance alone and in a batch gets the same bits.
                                    1 = every GEMM in one pass (the summation order of rounds 1-3) */
-    int32_t reserved[1];
+    int32_t mx_act_format;      /* EV_PREC_MX generator, format of the ACTIVATION operand in the two cross-term MFMAs where a kernel offers the choice (the fused
+                                   ResBlock pairs at 32 channels): 0 (default) = OCP E5M2 without block maxima -- Q(xh) = the top byte of the fp16 hi part,
+                                   Q(xl) = E5M2 of the remainder at the constant block scale 2^-11; per-element exponents, ~3x fewer quantiser instructions,
+                                   emulated waveform error 2 % LOWER than fp4's; 1 = block-scaled fp4 (e2m1) as in ABI <= 5.  Weights are fp4 planes either way. */
 } ev_config;
 
 /* Precision of the frame-rate path (ev_default_config: MX for both components).  F16: fp16 MFMA operands (what BASELINE.json's bf16 / fp16 configs name).

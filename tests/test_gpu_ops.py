@@ -689,6 +689,15 @@ def _mx_act_parts(a):
     return t(hi), t(mxfp4.dequantize(ch, sh, 32)), t(mxfp4.dequantize(cl, sl, 32)), (hi.astype(np.float16), ch, cl, sh, sl)
 
 
+def _e5_act_parts(a):
+    """a [rows][C] fp32 cpu -> (hi, Q(hi), Q(lo)) as fp64 in the maxima-free E5M2 operand format of ev_pair_e5.h (mxfp4.e5m2_*): Q(hi) = the top byte of the fp16 hi
+    part, Q(lo) = E5M2 of lo 2^11 at the constant scale 2^-11."""
+    from emotivoice_amd import mxfp4
+    hi, lo = mxfp4.split_hi_lo(a.numpy().astype(np.float32))
+    t = lambda z: torch.from_numpy(np.asarray(z, np.float64))          # noqa: E731
+    return t(hi), t(mxfp4.e5m2_decode(mxfp4.e5m2_hi_codes(hi))), t(mxfp4.e5m2_lo_decode(mxfp4.e5m2_lo_codes(lo))), None
+
+
 def _conv64(x_rows, w_ntk, dil, taps):
     """x [rows][K] fp64 (with halo rows), w [N][taps][K] fp64 -> valid conv [rows - (taps-1)*dil][N]."""
     return F.conv1d(x_rows.t().unsqueeze(0), w_ntk.permute(0, 2, 1).contiguous(), dilation=dil).squeeze(0).t()
@@ -1084,12 +1093,16 @@ def test_mx_plane_set_chain(lib, Cc, k, dil, up):
     assert torch.isfinite(outs[0]).all()
 
 
+@pytest.mark.parametrize("fmt", ["e5m2", "fp4"])
 @pytest.mark.parametrize("k,dil,acc_in", [(3, 1, False), (3, 5, True), (7, 3, False), (7, 1, True), (11, 5, True), (11, 1, False)])
-def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
-    """resblock_pair_c32_mx_kernel (ev_pair_mx.h): conv1(dil) -> leaky-relu -> conv2 + fp32 residual, every product as one fp16 MFMA +
-    two fp4 MFMAs (four taps per instruction), x fp32 in / fp32 out, the slab and the intermediate quantised in the kernel.  References in
-    fp64: (a) the same arithmetic with the host quantiser (mxfp4.py) -- tight; (b) the exact convs of models/hifigan/models.py:50-57 -- the
-    MX error level (~1e-4; fp16 operands give 5e-4)."""
+def test_fused_mx_resblock_pair(lib, k, dil, acc_in, fmt):
+    """The fused C = 32 pair: conv1(dil) -> leaky-relu -> conv2 + fp32 residual, every product as one fp16 MFMA + two block-scaled MFMAs for the
+    cross terms (four taps per instruction), x fp32 in / fp32 out, the slab and the intermediate quantised in the kernel.  fmt = the ACTIVATION
+    operand of the cross terms: "e5m2" = resblock_pair_c32_e5_kernel (ev_pair_e5.h, the default since round 6: top byte of the fp16 hi part +
+    E5M2 remainder at the constant scale 2^-11, no block maxima), "fp4" = resblock_pair_c32_mx*_kernel (ev_pair_mx.h, epi.reserved0 bit 4 /
+    ev_config.mx_act_format = 1).  References in fp64: (a) the same arithmetic with the host quantiser (mxfp4.py) -- tight; (b) the exact convs of
+    models/hifigan/models.py:50-57 -- the MX error level (~1e-4; fp16 operands give 5e-4)."""
+    FMT = 32 if fmt == "e5m2" else 16          # (32: the E5M2 kernel at every k -- the launcher itself picks it for k = 3 only)
     from emotivoice_amd import _ffi, mxfp4
     torch.manual_seed(300 + k + dil)
     Cc, M = 32, 5 * 256
@@ -1127,13 +1140,14 @@ def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
     if acc_in:
         e.acc32, e.ldacc = out.data_ptr(), Cc       # in place: the engine's running MRF sum
     e.out32, e.ldo = out.data_ptr(), Cc
+    e.reserved0 = FMT
     torch.cuda.synchronize()
     assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
     torch.cuda.synchronize()
     h = (k - 1) // 2
 
     def mxconv(a_rows, whd, wql, wqh, dd):
-        ah, qah, qal, _ = _mx_act_parts(a_rows.float())
+        ah, qah, qal, _ = (_e5_act_parts if fmt == "e5m2" else _mx_act_parts)(a_rows.float())
         return _conv64(ah, whd, dd, k) + _conv64(qah, wql, dd, k) + _conv64(qal, wqh, dd, k)
     xin = full.cpu()
     a0 = _lrelu(xin, 0.1)
@@ -1158,13 +1172,33 @@ def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
     assert _rel(got, res["emu"]) < 5e-5, (k, dil, _rel(got, res["emu"]))
     assert _rel(got, res["exact"]) < 2e-4, (k, dil, _rel(got, res["exact"]))
     assert _rel(res["emu"], res["exact"]) > 1e-6
-    # the two-group schedule (resblock_pair_c32_mx2_kernel: the launcher's choice above) against the lock-step kernel (epi.reserved0 bit 2): same
-    # arithmetic per output element, 128- instead of 256-row tiles -- bit-identical outputs
+    # the launcher's own choice (reserved0 = 0) is a rule on the layer's shape: E5M2 at k = 3, fp4 at k = 7 / 11
+    outd = acc.clone() if acc_in else torch.full((M, Cc), 7.0, device="cuda")
+    if acc_in:
+        e.acc32 = outd.data_ptr()
+    e.out32 = outd.data_ptr()
+    e.reserved0 = 0
+    assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(outd, out) == ((k == 3) == (fmt == "e5m2")), (k, fmt)
+    if fmt == "e5m2":
+        # the two formats are different arithmetic (the cross terms' last bits): E5M2 is the closer one to the exact convs on these data
+        outs4 = acc.clone() if acc_in else torch.full((M, Cc), 7.0, device="cuda")
+        if acc_in:
+            e.acc32 = outs4.data_ptr()
+        e.out32 = outs4.data_ptr()
+        e.reserved0 = 16
+        assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
+        torch.cuda.synchronize()
+        assert not torch.equal(out, outs4) and _rel(got, outs4.cpu().double()) < 2e-4
+        print("pair k=%d dil=%d: vs exact  e5m2 %.2e  fp4 %.2e" % (k, dil, _rel(got, res["exact"]), _rel(outs4.cpu().double(), res["exact"])))
+    # fp4: the two-group schedule (resblock_pair_c32_mx2_kernel) against the lock-step kernel (epi.reserved0 bit 2): same arithmetic per output element, 128-
+    # instead of 256-row tiles -- bit-identical outputs
     out2 = acc.clone() if acc_in else torch.full((M, Cc), 7.0, device="cuda")
     if acc_in:
         e.acc32 = out2.data_ptr()
     e.out32 = out2.data_ptr()
-    e.reserved0 = 4
+    e.reserved0 = FMT | 4
     torch.cuda.synchronize()
     assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
     torch.cuda.synchronize()
@@ -1176,7 +1210,7 @@ def test_fused_mx_resblock_pair(lib, k, dil, acc_in):
         if acc_in:
             e.acc32 = out3.data_ptr()
         e.out32 = out3.data_ptr()
-        e.reserved0 = dbg
+        e.reserved0 = FMT | dbg
         torch.cuda.synchronize()
         assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
         torch.cuda.synchronize()

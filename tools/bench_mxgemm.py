@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--valid-shift", type=int, default=-1, help=">= 0: pass a row_valid table (one byte per 2^shift rows, the engine's frame validity: stage 1 = 6, stage 0 = 3) with "
                     "every 129th 256-row tile all-gap, as in a B = 32 x 1024-frame forward")
+    ap.add_argument("--timeline", action="store_true", help="EV_MXT build (EVHIP_LIB=.../libevhip_mxt.so): chip-wide timeline of the blocks' main loops and epilogues")
     ap.add_argument("--dbg", default="", help="comma list of reserved0 low bits to A/B in one run (8 = one block per tile instead of the persistent tile loop)")
     args = ap.parse_args()
     lib = _ffi.lib()
@@ -97,6 +98,36 @@ def main():
                 e1.record(st)
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / args.reps * 1e3
+                if args.timeline and abl == 0:
+                    nblk = (M // 256) * (Cc // 128)
+                    tb = torch.zeros(nblk * 4, device="cuda", dtype=torch.int64)
+                    d.row_seq = tb.data_ptr()
+                    lib.ev_op_conv_gemm(C.byref(d), C.c_void_p(st.cuda_stream))
+                    torch.cuda.synchronize()
+                    d.row_seq = None
+                    t = tb.cpu().numpy().reshape(nblk, 4)
+                    t0, t1, t2 = (t[:, i].astype(np.float64) for i in range(3))
+                    base = t0.min()
+                    t0, t1, t2 = (t0 - base) / 100.0, (t1 - base) / 100.0, (t2 - base) / 100.0          # us
+                    live = (t2 - t0) > 1.0          # (all-gap tiles skip the K loop)
+                    total = t2.max()
+                    print("   timeline: %d blocks, launch %.1f us | tile life %.1f us (main %.1f + epilogue %.1f; p10 / p90 of the epilogue %.1f / %.1f)" %
+                          (nblk, total, (t2 - t0)[live].mean(), (t1 - t0)[live].mean(), (t2 - t1)[live].mean(), np.percentile((t2 - t1)[live], 10), np.percentile((t2 - t1)[live], 90)))
+                    # how many blocks are resident / inside their epilogue over time (1-us bins)
+                    bins = np.arange(0, total + 1.0, 1.0)
+                    res_n = np.zeros(len(bins)); epi_n = np.zeros(len(bins))
+                    for a_, b_, arr in ((t0, t2, res_n), (t1, t2, epi_n)):
+                        np.add.at(arr, np.clip(a_.astype(int), 0, len(bins) - 1), 1)
+                        np.add.at(arr, np.clip(b_.astype(int), 0, len(bins) - 1), -1)
+                    res_c, epi_c = np.cumsum(res_n), np.cumsum(epi_n)
+                    mid = slice(int(0.1 * len(bins)), int(0.9 * len(bins)))
+                    frac = epi_c[mid] / np.maximum(res_c[mid], 1)
+                    print("   resident blocks (mid 80 %% of the launch): mean %.0f | in their epilogue: mean %.0f = %.2f of the resident ones, min %.2f, max %.2f, std %.2f" %
+                          (res_c[mid].mean(), epi_c[mid].mean(), frac.mean(), frac.min(), frac.max(), frac.std()))
+                    # first-round skew: start times of the first 512 blocks, and block lifetimes by round
+                    order = np.argsort(t0)
+                    print("   starts of the first 512 blocks: %.1f .. %.1f us; epilogue length by start-time decile: %s" %
+                          (t0[order[0]], t0[order[min(511, nblk - 1)]], " ".join("%.1f" % (t2 - t1)[order[i * nblk // 10:(i + 1) * nblk // 10]].mean() for i in range(10))))
                 fl = 2.0 * M * Cc * Cc * k
                 by = M * Cc * (3.0625 * 2 + (8 if form == "conv2" else (2.53 if form == "conv2pl" else 0)))
                 print("C=%d M=%d k=%2d %-5s %-24s %8.1f us  %6.0f TF/s alg  %5.2f TB/s contract" % (Cc, M, k, form, nm, us, fl / us / 1e6, by / us / 1e6), flush=True)

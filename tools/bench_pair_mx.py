@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Times resblock_pair_c32_mx*_kernel (ev_pair_mx.h) on stage 3 of the B = 32 x 256-phoneme forward (8.45 M rows x 32 channels, fp32 in / out) with in-process
-A/B over ev_conv_gemm_desc.reserved0 (0 = the launcher's choice (two groups per block), 4 = the lock-step kernel; 8 selected two groups in the round-5 build that tried three) and a bit
-comparison of the outputs.
+"""Times the fused C = 32 ResBlock pair on stage 3 of the B = 32 x 256-phoneme forward (8.45 M rows x 32 channels, fp32 in / out) with in-process A/B over
+ev_res_pair_desc.epi.reserved0: 0 = the launcher's default (round 6: resblock_pair_c32_e5_kernel, E5M2 activation operands, ev_pair_e5.h, at k = 3; the fp4 kernel at k = 7 / 11), 32 = E5M2 at every k; 16 = block-scaled fp4
+activation operands (resblock_pair_c32_mx2_kernel, ev_pair_mx.h: rounds 3-5), 16 + 4 = its lock-step form, 16 + 8 = its round-4 instruction stream (the kernel's
+r4_paths switch).  Outputs of one format are compared bit for bit with the first run of that format (the two formats differ in the cross terms' last bits).
 
     python tools/bench_pair_mx.py [--ks 3,7,11] [--dbg 0,8,0,8,4]"""
 import argparse
@@ -21,9 +22,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ks", default="3")
     ap.add_argument("--dils", default="1,3,5")
-    ap.add_argument("--dbg", default="0,8,0,8,4")
+    ap.add_argument("--dbg", default="0,16,0,16")
     ap.add_argument("--rows", type=int, default=33024 * 256)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--timing", action="store_true", help="EV_PAIR_TIMING build (EVHIP_LIB=.../libevhip_ptime.so): print where a wave's cycles go (default format only)")
     a = ap.parse_args()
     lib = _ffi.lib()
     Cc, M, PAD = 32, a.rows, 64
@@ -57,6 +59,9 @@ def main():
                     if acc_in:
                         e.acc32, e.ldacc = acc.data_ptr(), Cc          # (not in place here: repeated launches must see the same addend)
                     e.reserved0 = dbg
+                    tbuf = torch.zeros(256 * 8 * 16, device="cuda", dtype=torch.int32) if a.timing else None
+                    if a.timing:
+                        e.row_seq = tbuf.data_ptr()
                     for _ in range(2):
                         assert lib.ev_op_resblock_pair_c32_mx(C.byref(d), None) == 0
                     torch.cuda.synchronize()
@@ -67,10 +72,26 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / a.iters
+                    if a.timing and (dbg & 32):
+                        tbuf.zero_()
+                        lib.ev_op_resblock_pair_c32_mx(C.byref(d), None)
+                        torch.cuda.synchronize()
+                        t = tbuf.cpu().numpy().view(np.uint32).reshape(256, 8, 16).astype(np.float64)
+                        ok = t[:, :, 15] == 0xC0FFEE
+                        names = ["loads issue", "conv1", "xt quant", "barrier A", "slab->LDS", "conv2", "epilogue", "barrier B", "prologue"]
+                        bmo = 128 - (k - 1)
+                        iters = math.ceil(math.ceil(M / bmo) / 512)
+                        for gname, sl in (("group 0", slice(0, 4)), ("group 1", slice(4, 8))):
+                            m = t[:, sl, :9][ok[:, sl]].mean(axis=0)
+                            print("   %s (%d waves, %d iterations): per iteration " % (gname, int(ok[:, sl].sum()), iters) +
+                                  " | ".join("%s %.0f" % (n, v / iters) for n, v in zip(names[:8], m[:8])) + " | total %.0f ticks; prologue %.0f" % (m[:8].sum() / iters, m[8]))
                     if first is None:
-                        first, same = out.clone(), ""
+                        first = {}
+                    fk = 'e5' if (dbg & 32) or (k == 3 and not (dbg & 16)) else 'fp4'
+                    if fk not in first:
+                        first[fk], same = out.clone(), ""
                     else:
-                        nbad = int((out.view(torch.int32) != first.view(torch.int32)).sum())
+                        nbad = int((out.view(torch.int32) != first[fk].view(torch.int32)).sum())
                         same = "  bits == first" if nbad == 0 else "  %d ELEMENTS DIFFER" % nbad
                     fl = 2.0 * 2.0 * M * Cc * Cc * k
                     print("k=%2d dil=%d acc_in=%d dbg=%d  %8.1f us  %6.1f TF/s alg  %5.2f TB/s (x in + out%s)%s" %
