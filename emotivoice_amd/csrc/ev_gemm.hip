@@ -395,6 +395,16 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
     constexpr int TC = NT * 16;
     constexpr bool SWZ = RP == 16;
     constexpr int PITCH = SWZ ? TC * 4 : epi_pitch<TC>();
+    // EV_MXT (tuning build, tools/bench_mxgemm.py --timeline): s_memtime at the entry, in front of the pass loop, inside every pass (scratch written + read back
+    // issued, i.e. behind the pass's operand requests) and behind every pass; lane 0 of every wave dumps them behind the blocks' records of conv_gemm_mx_kernel
+#ifdef EV_MXT
+    unsigned long long mxt_e[12];
+    int mxt_i = 0;
+#define EV_MXT_STAMP() { __builtin_amdgcn_sched_barrier(0); mxt_e[mxt_i++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define EV_MXT_STAMP()
+#endif
+    EV_MXT_STAMP()
     constexpr int LPR = TC / 8, RPI = 64 / LPR, IT = RP / RPI, NP = MT * 16 / RP, NG = MT / 2;
     static_assert((RP == 32 || (RP == 16 && TC == 64)) && IT >= 1, "rows per pass");
     int lane_ = threadIdx.x & 63;
@@ -523,6 +533,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
         mx_sstep = 4 * (p.mxo_logC ? (p.ldo >> p.mxo_logC) : 1);
     }
     EV_STAMP()
+    EV_MXT_STAMP()
 
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
@@ -666,7 +677,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
             }
             EV_STAMP()
         }
+        if constexpr (SWZ) { EV_MXT_STAMP() }
     }
+#ifdef EV_MXT
+    if constexpr (SWZ) {
+        if (p.row_seq && lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(p.row_seq)) + (size_t)gridDim.x * 4 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;
+            for (int i = 0; i < 2 + NP && i < 8; ++i) o[i] = mxt_e[i];
+        }
+    }
+#endif
+#undef EV_MXT_STAMP
 #undef EV_EPI_PREFETCH
 #undef EV_EPI_SET
 #undef EV_EPI_RD

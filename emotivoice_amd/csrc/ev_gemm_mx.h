@@ -340,6 +340,8 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
 #endif
 #ifdef EV_MXT
     const unsigned long long mxt1 = __builtin_amdgcn_s_memrealtime();
+    if (p.reserved0 & 1) __builtin_amdgcn_s_setprio(3);          // A/B (tools/bench_mxgemm.py --dbg 1): the epilogue above the partner block's matrix phases
+    if (p.reserved0 & 2) __builtin_amdgcn_s_setprio(1);          // ... or level with them
 #endif
     if constexpr (EPI == EPI_GENERIC) gemm_epilogue_lds<MT, NT>(p, acc, smem + wave * epi_wave_bytes<TC>(), m0 + wt * 64, n0 + wc * TC);
     else {

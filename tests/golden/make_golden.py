@@ -106,6 +106,13 @@ CASES = {
     # from O(1) to rms 540 / max 2.5e3 (synthetic.HOT_*) -- what fp16 storage has to survive with a released checkpoint
     "n256_zero_dc": (0, "parity_zdc", 17, [256], [8]),
     "n64_hot_zdc": (0, "parity_zdc_hot", 18, [64], [321]),
+    # round 6: a second and a third DRAW OF THE WEIGHTS (every fixture above is weight seed 0): the block-scaled / E5M2 cross terms' error depends on block maxima
+    # and on the activations' growth through the generator, i.e. on the weights -- a margin measured on one draw is one sample.  Zero-mean waveforms, plain and
+    # trained-like gains, conv_post re-calibrated per seed (synthetic.ZDC_POST_BIAS_BY_SEED / HOT_POST_*_BY_SEED, tools/calibrate_hot.py --seed N)
+    "n96_zero_dc_w1": (1, "parity_zdc", 19, [96], [45]),
+    "n64_hot_zdc_w1": (1, "parity_zdc_hot", 20, [64], [1001]),
+    "n96_zero_dc_w2": (2, "parity_zdc", 21, [96], [777]),
+    "n64_hot_zdc_w2": (2, "parity_zdc_hot", 22, [64], [3]),
 }
 
 

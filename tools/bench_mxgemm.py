@@ -100,12 +100,14 @@ def main():
                 us = e0.elapsed_time(e1) / args.reps * 1e3
                 if args.timeline and abl == 0:
                     nblk = (M // 256) * (Cc // 128)
-                    tb = torch.zeros(nblk * 4, device="cuda", dtype=torch.int64)
+                    tb = torch.zeros(nblk * 4 + nblk * 64, device="cuda", dtype=torch.int64)
                     d.row_seq = tb.data_ptr()
                     lib.ev_op_conv_gemm(C.byref(d), C.c_void_p(st.cuda_stream))
                     torch.cuda.synchronize()
                     d.row_seq = None
-                    t = tb.cpu().numpy().reshape(nblk, 4)
+                    tall = tb.cpu().numpy()
+                    t = tall[:nblk * 4].reshape(nblk, 4)
+                    te = tall[nblk * 4:].reshape(nblk, 8, 8).astype(np.float64)
                     t0, t1, t2 = (t[:, i].astype(np.float64) for i in range(3))
                     base = t0.min()
                     t0, t1, t2 = (t0 - base) / 100.0, (t1 - base) / 100.0, (t2 - base) / 100.0          # us
@@ -124,6 +126,11 @@ def main():
                     frac = epi_c[mid] / np.maximum(res_c[mid], 1)
                     print("   resident blocks (mid 80 %% of the launch): mean %.0f | in their epilogue: mean %.0f = %.2f of the resident ones, min %.2f, max %.2f, std %.2f" %
                           (res_c[mid].mean(), epi_c[mid].mean(), frac.mean(), frac.min(), frac.max(), frac.std()))
+                    # inside the epilogue (s_memtime ticks per wave): setup (bias / row-valid loads, address arithmetic), then the four 16-row passes
+                    lv = live[:, None] & (te[:, :, 0] > 0)
+                    dd = np.diff(te[:, :, :6], axis=2)
+                    print("   epilogue per wave (s_memtime ticks): setup %.0f | passes %s | total %.0f" %
+                          (dd[:, :, 0][lv].mean(), " ".join("%.0f" % dd[:, :, 1 + i][lv].mean() for i in range(4)), (te[:, :, 5] - te[:, :, 0])[lv].mean()))
                     # first-round skew: start times of the first 512 blocks, and block lifetimes by round
                     order = np.argsort(t0)
                     print("   starts of the first 512 blocks: %.1f .. %.1f us; epilogue length by start-time decile: %s" %

@@ -1,5 +1,9 @@
 #!/bin/bash
-# Scratch runner for one-off GPU experiments:  gpurun --timeout N -- 'bash tools/gpu_quick.sh'
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -s -k "fused_mx_resblock_pair and not c64" --timeout 600 > gpurun_out/ops_pair.log 2>&1; echo "ops rc=$?"; grep -E "passed|failed|Error|assert" gpurun_out/ops_pair.log | head -40
-timeout 600 python tools/bench_pair_mx.py --ks 3,7,11 --dils 1,5 --dbg 0,16,0,16 2>&1 | grep -v amdgpu.ids > gpurun_out/pair_e5_ab.txt; echo "ab rc=$?"; cut -c1-160 gpurun_out/pair_e5_ab.txt
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 900 -k "(golden and (w1 or w2)) or weight_draws" > gpurun_out/parity_draws.log 2>&1; echo "rc=$?"; tail -n 15 gpurun_out/parity_draws.log | cut -c1-300
+python - <<'PY'
+import json
+r=json.load(open("gpurun_out/parity_report.json"))
+for k,v in sorted(r.items()):
+    if "w1" in k or "w2" in k or "draw" in k: print(k, {a:(round(b,6) if isinstance(b,float) else b) for a,b in v.items()})
+PY

@@ -211,10 +211,11 @@ def main():
     ap.add_argument("--weights", default="parity", help="synthetic weight recipe: parity (conv_post bias re-centred here for a zero-mean waveform) or "
                                                         "parity_zdc_hot (trained-like gains, the worst reference fixture's recipe)")
     ap.add_argument("--only", default=None, help="substring filter on the recipe names")
+    ap.add_argument("--wseed", type=int, default=0, help="weight seed (round 6: the parity suite runs three draws of the weights)")
     args = ap.parse_args()
     torch.set_num_threads(8)
     shapes = EVShapes()
-    sd = to_torch_sd(synth_state_dict(0, args.weights))
+    sd = to_torch_sd(synth_state_dict(args.wseed, args.weights))
     utt = synth_inputs(args.seed, [args.phonemes], [7])[0]
     with torch.no_grad():
         am = am_forward(sd, torch.from_numpy(utt["ling"]), 7, torch.from_numpy(utt["style"]), torch.from_numpy(utt["content"]), shapes)
