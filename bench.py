@@ -84,12 +84,14 @@ PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICRO
 PEAK_MFMA_FP4 = 10000.0                            # TFLOP/s dense, block-scaled fp4 / fp6 (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0                                  # GB/s
 DTYPE_NAME = {"f16": "f16", "x3": "f16x3 (fp16 hi/lo split, 3 MFMAs per product, fp32 activations)",
-              "mx": "f16+mxfp4 (fp32 activations; per product one fp16 MFMA on the hi parts + two block-scaled fp4 MFMAs for the cross terms; "
-                    "split-precision fp16x3 where channels < 128 and in the mel decoder)"}
-# measured DC-free relative L2 of the waveform against the reference's own outputs (tests/test_gpu_parity.py, profiles/r3_h_parity_report.json)
-PARITY_LEVEL = {"mx": "<= 5.5e-4 on every fixture incl. zero-mean and trained-like gains (bar 1e-3)", "fast": "2.4e-3 on zero-mean audio (bar 1e-3: NOT met)",
-                "strict": "<= 3e-6"}
-REFERENCE_CPU_FRAMES_PER_S = 628.0                 # the reference's own JETSGenerator, 8 Xeon cores, B = 1, N = 256
+              "mx": "f16+mxfp4 (fp32-class activations travelling as plane sets; per product one fp16 MFMA on the hi parts + two block-scaled MFMAs for the cross "
+                    "terms: fp4 x fp4 in every generator stage, the decoder's conv-FFN and QKV / output projections, fp4 weights x E5M2 activations in the fused "
+                    "32-channel k = 3 pairs; split-precision fp16x3 only in the decoder's attention and LayerNorm-side glue and in the token-rate path)"}
+# measured DC-free relative L2 of the waveform against the reference's own outputs (tests/test_gpu_parity.py; profiles/r6_c_parity_report.json: the 8 fixtures of
+# weight seed 0; profiles/r6_d_parity_weight_draws.json: the second and third draw of the weights, round 6)
+PARITY_LEVEL = {"mx": "<= 4.8e-4 on the 8 reference fixtures of weight seed 0 (zero-mean and trained-like gains included); over three draws of the weights the worst case "
+                      "is 8.8e-4 (seed 1, trained-like gains: that draw is 1.7x harder in every mode) -- bar 1e-3",
+                "fast": "2.4e-3 ... 4.3e-3 on zero-mean audio (bar 1e-3: NOT met)", "strict": "<= 5e-6"}
 
 
 def reference_cpu_record():
@@ -150,10 +152,9 @@ def cpu_baseline(n_utts, phonemes, threads=16):
     dt = time.perf_counter() - t0
     return dict(value=frames / dt, unit="mel-frames/s", cores=cores, kind="port",
                 sample="%d utterances x %d phonemes, B=1 loop, fp32 torch-CPU oracle, %.1f s" % (done, phonemes, dt),
-                reference_measured_elsewhere=dict(value=REFERENCE_CPU_FRAMES_PER_S, unit="mel-frames/s", cores=8,
-                                                  note="the reference's own JETSGenerator module (kind 'reference') timed in the build "
-                                                       "container, SURVEY.md section 6; /root/reference does not exist on the GPU box",
-                                                  current=reference_cpu_record()))
+                # (one figure, one source: the committed record of tools/time_reference.py -- SURVEY section 6's preliminary 628 frames/s is superseded by it)
+                reference_measured_in_build_container=dict(note="the reference's own JETSGenerator module (kind 'reference') timed on the BUILD CONTAINER's 8 cores, "
+                                                                "not on this box; /root/reference does not exist on the GPU box", **(reference_cpu_record() or {})))
 
 
 class Workload:
@@ -240,7 +241,8 @@ def b1_latency(eng, phonemes=(64, 256)):
         for nph in phonemes:
             r = ref.get("%dph" % nph)
             if r:
-                lat["b1_%dph_speedup_vs_cpu_reference" % nph] = round(r["ms_per_utterance"] / lat["b1_%dph_ms" % nph], 1)
+                # (a committed timing from ANOTHER machine -- the build container's 8 cores -- over this box's live GPU latency: named for what it is)
+                lat["b1_%dph_speedup_vs_build_container_reference" % nph] = round(r["ms_per_utterance"] / lat["b1_%dph_ms" % nph], 1)
     return lat
 
 

@@ -132,31 +132,45 @@ class DynamicBatcher:
         first = self._carry.pop(0) if self._carry else self._q.get()
         if first is None:
             return []
-        batch, tokens = [first], len(first.ling)
-        deadline = time.perf_counter() + self.max_wait
-        keep = []
-        for r in self._carry:                           # carried requests first (they have waited longest)
-            if r.alpha == first.alpha and len(batch) < self.max_batch and tokens + len(r.ling) <= self.max_tokens:
-                batch.append(r); tokens += len(r.ling)
-            else:
-                keep.append(r)
-        self._carry = keep
-        while len(batch) < self.max_batch and tokens < self.max_tokens:
-            timeout = deadline - time.perf_counter()
-            if timeout <= 0:
-                break
-            try:
-                r = self._q.get(timeout=timeout)
-            except queue.Empty:
-                break
-            if r is None:
-                self._q.put(None)
-                break
-            if r.alpha == first.alpha and tokens + len(r.ling) <= self.max_tokens:
-                batch.append(r); tokens += len(r.ling)
-            else:
-                self._carry.append(r)
-        return batch
+        batch = [first]
+        cur = first                                         # the request whose fields are being looked at (the one to blame if that raises)
+        try:
+            tokens = len(first.ling)
+            deadline = time.perf_counter() + self.max_wait
+            keep = []
+            for r in self._carry:                           # carried requests first (they have waited longest)
+                cur = r
+                if r.alpha == first.alpha and len(batch) < self.max_batch and tokens + len(r.ling) <= self.max_tokens:
+                    batch.append(r); tokens += len(r.ling)
+                else:
+                    keep.append(r)
+            self._carry = keep
+            while len(batch) < self.max_batch and tokens < self.max_tokens:
+                timeout = deadline - time.perf_counter()
+                if timeout <= 0:
+                    break
+                try:
+                    r = self._q.get(timeout=timeout)
+                except queue.Empty:
+                    break
+                if r is None:
+                    self._q.put(None)
+                    break
+                batch.append(r)                             # (taken off the queue: from here on it is somebody's responsibility)
+                cur = r
+                if r.alpha == first.alpha and tokens + len(r.ling) <= self.max_tokens:
+                    tokens += len(r.ling)
+                else:
+                    batch.pop()
+                    self._carry.append(r)
+            return batch
+        except Exception:
+            # a malformed request (e.g. no usable ``ling``) blew up the collection: what was already taken off the queue / the carry list goes
+            # back to the carry list, minus the offender, which fails alone -- nobody is left waiting
+            rest = [r for r in batch if r is not cur]
+            self._carry = rest + [r for r in self._carry if r is not cur and all(r is not x for x in rest)]
+            _resolve(cur.future, exception=RuntimeError("request could not be batched (malformed fields)"))
+            raise
 
     def _run(self, batch: List[SynthesisRequest]):
         if self.embed_batch_fn is not None:

@@ -234,6 +234,39 @@ def test_loop_error_fails_the_batch_it_dropped_and_backs_off(caplog):
     b.close()
 
 
+def test_error_inside_take_batch_leaves_nobody_waiting():
+    """an exception raised INSIDE _take_batch (after it has pulled requests off the queue into its local list) used to drop those requests
+    unresolved -- the loop's catch-all only saw an empty batch.  Now the offender at the head fails alone and what was collected goes back to the carry list."""
+    import threading
+    from emotivoice_amd.serving import SynthesisRequest
+    gate = threading.Event()
+
+    def synth(utts, alpha):
+        gate.wait(5)
+        return [np.zeros(4, np.float32) for _ in utts]
+    b = DynamicBatcher(synth, max_batch=4, max_wait_ms=200)
+    first = b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768))          # occupies the worker until the gate opens
+
+    class NoLen:                                     # a request whose ``ling`` cannot be measured: len() raises inside _take_batch
+        def __len__(self):
+            raise TypeError("no length")
+    time.sleep(0.05)
+    bad = SynthesisRequest.__new__(SynthesisRequest)
+    bad.__dict__.update(ling=NoLen(), speaker=0, style=np.zeros(768), content=np.zeros(768), alpha=1.0)
+    from concurrent.futures import Future
+    bad.future = Future()
+    b._q.put(bad)                                    # (submit() validates; this stands for any field that breaks the collection loop)
+    good = [b.submit(np.arange(3), 0, np.zeros(768), np.zeros(768)) for _ in range(2)]
+    gate.set()
+    assert first.result(timeout=5).shape == (4,)
+    with pytest.raises(Exception):
+        bad.future.result(timeout=5)
+    for g in good:
+        assert g.result(timeout=5).shape == (4,)     # collected behind the offender or still queued: served either way
+    assert b._thread.is_alive()
+    b.close()
+
+
 def test_close_with_a_busy_worker_leaves_it_its_sentinel():
     """close() whose join timed out used to drain the queue -- sentinel included -- so the worker blocked forever after its
     batch and its carried requests were never failed.  Now a live worker keeps the queue: it finishes, sees the sentinel and exits."""

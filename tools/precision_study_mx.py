@@ -97,7 +97,11 @@ LO_FIXED = [False]          # set per recipe by emulate()
 
 class Recipe:
     def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None, mrf16=False,
-                 engine_flow=False, mrf_planes=None, lo_fixed=False, e5m2_stages=(), e5m2_rne=False):
+                 engine_flow=False, mrf_planes=None, lo_fixed=False, e5m2_stages=(), e5m2_rne=False, exact_stages=(), cross_w=None, cross_x=None):
+        # cross_w / cross_x: attribution -- override the format of the WEIGHT / ACTIVATION side of the cross terms ("f16" = exact lo parts)
+        self.cross_w, self.cross_x = cross_w, cross_x
+        # exact_stages: attribution -- the convs of these generator stages evaluate their cross terms exactly (fp16 lo parts), everything else as the recipe says
+        self.exact_stages = tuple(exact_stages)
         # e5m2_stages: generator stages (0-3; conv_pre / the up-conv INTO stage i count as stage i's input) whose ACTIVATION cross-term operands are E5M2
         # without block maxima (weights stay block-scaled fp4): Q(xh) = top byte of the fp16 hi plane, Q(xl) = E5M2 of xl 2^11 at the constant scale 2^-11;
         # a residual rebuilt from planes in such a stage uses hi + that E5M2 remainder
@@ -125,7 +129,7 @@ def planes_roundtrip(x, fmt):
     return torch.where(a2 >= 0, a2, a2 * 10.0)
 
 
-def conv_mx(x, w, b, rc, transposed=False, e5m2=False, **kw):
+def conv_mx(x, w, b, rc, transposed=False, e5m2=False, exact=False, **kw):
     """x [1, C, T] fp32, w fp32.  hi.hi in fp16 operands + cross terms in rc.cross (None = omitted, 'f16' = fp16 exact)."""
     op = F.conv_transpose1d if transposed else F.conv1d
     xh, wh = r16(x), r16(w)
@@ -134,10 +138,14 @@ def conv_mx(x, w, b, rc, transposed=False, e5m2=False, **kw):
         return y
     xl, wl = x - xh, w - wh
     kdim_w = 0 if transposed else 1      # conv_transpose weight is [Cin, Cout, k]
-    if rc.cross == "f16":
+    if rc.cross == "f16" or exact:
         qa = qb = lambda t, d: r16(t)
     else:
         qa = qb = lambda t, d: mx_quant(t, rc.cross, d)
+        if getattr(rc, "cross_x", None):
+            qa = (lambda t, d: r16(t)) if rc.cross_x == "f16" else (lambda t, d: mx_quant(t, rc.cross_x, d))
+        if getattr(rc, "cross_w", None):
+            qb = (lambda t, d: r16(t)) if rc.cross_w == "f16" else (lambda t, d: mx_quant(t, rc.cross_w, d))
     if e5m2:
         return y + op(e5m2_hi(xh, rc.e5m2_rne), qb(wl, kdim_w), None, **kw) + op(e5m2_lo(xl), qb(wh, kdim_w), None, **kw)
     if "xh_wl" in rc.lo_terms:
@@ -158,7 +166,7 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
     stage = [0]
 
     def conv(x, name, **kw):
-        return conv_mx(x, fold_weight_norm(sd, name), sd[name + ".bias"], rc, e5m2=stage[0] in rc.e5m2_stages, **kw)
+        return conv_mx(x, fold_weight_norm(sd, name), sd[name + ".bias"], rc, e5m2=stage[0] in rc.e5m2_stages, exact=stage[0] in rc.exact_stages, **kw)
 
     x = mel_ct.unsqueeze(0)
     x = st(conv(x, prefix + ".conv_pre", padding=3))
@@ -172,7 +180,7 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
                 st = (lambda t: t)
         x = F.leaky_relu(x, 0.1)
         # the up-conv INTO stage i reads stage i - 1's output planes
-        x = conv_mx(x, fold_weight_norm(sd, f"{prefix}.ups.{i}"), sd[f"{prefix}.ups.{i}.bias"], rc, transposed=True, e5m2=max(i - 1, 0) in rc.e5m2_stages,
+        x = conv_mx(x, fold_weight_norm(sd, f"{prefix}.ups.{i}"), sd[f"{prefix}.ups.{i}.bias"], rc, transposed=True, e5m2=max(i - 1, 0) in rc.e5m2_stages, exact=max(i - 1, 0) in rc.exact_stages,
                     stride=u, padding=(k - u) // 2)
         x = st(x)
         xs = None
@@ -254,6 +262,15 @@ def main():
             Recipe("E5M2 r6: stages 2 + 3 (nearest)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(2, 3), e5m2_rne=True),
             Recipe("E5M2 r6: every stage (truncated)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(0, 1, 2, 3)),
             Recipe("E5M2 r6: every stage (nearest)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", e5m2_stages=(0, 1, 2, 3), e5m2_rne=True),
+            Recipe("ATTR r6: ENGINE + MRF partials, stage 0 cross terms exact", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", exact_stages=(0,)),
+            Recipe("ATTR r6: stage 1 exact", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", exact_stages=(1,)),
+            Recipe("ATTR r6: stage 2 exact", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", exact_stages=(2,)),
+            Recipe("ATTR r6: stage 3 exact", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", exact_stages=(3,)),
+            Recipe("ATTR r6: every stage's cross terms exact (what the plane-set residual / MRF partials alone cost)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", exact_stages=(0, 1, 2, 3)),
+            Recipe("ATTR r6: fp4 cross terms, fp32 residual and MRF sums (what the cross terms alone cost)", "fp4"),
+            Recipe("ATTR r6: fp32 residual / MRF, fp4 ACTIVATION codes, exact weight lo parts", "fp4", cross_w="f16"),
+            Recipe("ATTR r6: fp32 residual / MRF, exact activation parts, fp4 WEIGHT codes", "fp4", cross_x="f16"),
+            Recipe("ATTR r6: fp32 residual / MRF, fp4 activations, fp6 weights", "fp4", cross_w="fp6"),
             Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
             Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
         ]
