@@ -267,7 +267,7 @@ VOC_FAMILIES = {
     "voc_conv_gemm_mx": (1.5, "conv_gemm_mx_kernel: one fp16 MFMA + two block-scaled fp4 MFMAs (4x rate) per product, operand planes from the producer's epilogue"),
     "voc_conv_c64_mx": (1.5, "conv_c64_mx_kernel (stage 2, C = 64: two taps per fp4 MFMA, plane sets in / out)"),
     "voc_resblock_pair_c64_mx": (1.5, "resblock_pair_c64_mx_kernel (fused k = 3 pair of stage 2, plane sets in / out, xt and the residual never cross HBM)"),
-    "voc_resblock_pair_c32_mx": (1.5, "resblock_pair_c32_mx_kernel (fused pair, fp16 + fp4 MFMAs, fp32 in / out)"),
+    "voc_resblock_pair_c32_mx": (1.5, "resblock_pair_c32_e5_kernel at k = 3 (fp4 weights x E5M2 activations) / resblock_pair_c32_mx2_kernel at k = 7, 11 (fused pair, fp16 + block-scaled MFMAs, fp32 in / out)"),
 }
 DOMINANT = {"f16": "voc_conv_gemm_f16", "x3": "voc_conv_gemm_x3", "mx": "voc_conv_gemm_mx"}
 
@@ -532,6 +532,7 @@ def main():
     ap.add_argument("--mx-residual", default="planes", choices=["planes", "fp32"], help="ev_config.mx_residual (A/B: round 3's fp32 residual stream)")
     ap.add_argument("--mx-mrf", default="planes", choices=["planes", "fp32"], help="ev_config.mx_mrf (A/B: fp32 running MRF sum)")
     ap.add_argument("--decoder-ln", default="planes", choices=["planes", "fp32"], help="ev_config.decoder_ln_planes (A/B: fp32 LayerNorm output + planes pass)")
+    ap.add_argument("--mx-act-format", default="e5m2", choices=["e5m2", "fp4"], help="ev_config.mx_act_format (A/B: activation operand of the cross terms in the fused 32-channel k = 3 pairs)")
     ap.add_argument("--token-splitk", default="on", choices=["on", "off"], help="ev_config.token_splitk (A/B: the token-rate long-K GEMMs in one pass)")
     ap.add_argument("--precision", default="mx", choices=["mx", "fast", "strict"],
                     help="frame-rate path: mx (default, the contract mode: waveform <= 1e-3 on every fixture) = fp32 activations, one fp16 MFMA + "
@@ -592,7 +593,7 @@ def main():
     def make_engine(precision, decoder_precision=None):
         e = EVEngine(device_id=local_rank, precision=precision, decoder_precision=decoder_precision,
                      vocoder_chunk_mb=args.chunk_mb, vocoder_streams=args.voc_streams, mx_residual=args.mx_residual,
-                     mx_mrf=args.mx_mrf, decoder_ln=args.decoder_ln, token_splitk=args.token_splitk == "on")
+                     mx_mrf=args.mx_mrf, decoder_ln=args.decoder_ln, token_splitk=args.token_splitk == "on", mx_act_format=args.mx_act_format)
         e.load_blob_device(blob_t.data_ptr(), blob_t.numel(), keepalive=blob_t)
         return e
 

@@ -95,8 +95,9 @@ def _engine(wmode, prec="fast", keep=True):
     if key not in _CACHE:
         dp, vp = MODES[prec]
         # "mx32": round 3's flow -- fp32 residual stream, and (round 4) the token-rate conv-FFN in one pass instead of split-K: the opt-outs stay under test
+        # ... and (round 6) block-scaled fp4 activation operands in the fused 32-channel k = 3 pairs instead of E5M2 (ev_config.mx_act_format = 1)
         eng = EVEngine(decoder_precision=dp, vocoder_precision=vp, keep_stages=keep, mx_residual="fp32" if prec == "mx32" else "planes",
-                       token_splitk=prec != "mx32")
+                       token_splitk=prec != "mx32", mx_act_format="fp4" if prec == "mx32" else "e5m2")
         _, blob, man = _weights(wmode)
         eng.load_blob(blob, man)
         _CACHE[key] = eng

@@ -97,9 +97,11 @@ LO_FIXED = [False]          # set per recipe by emulate()
 
 class Recipe:
     def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None, mrf16=False,
-                 engine_flow=False, mrf_planes=None, lo_fixed=False, e5m2_stages=(), e5m2_rne=False, exact_stages=(), cross_w=None, cross_x=None):
+                 engine_flow=False, mrf_planes=None, lo_fixed=False, e5m2_stages=(), e5m2_rne=False, exact_stages=(), cross_w=None, cross_x=None, res32_stages=()):
         # cross_w / cross_x: attribution -- override the format of the WEIGHT / ACTIVATION side of the cross terms ("f16" = exact lo parts)
         self.cross_w, self.cross_x = cross_w, cross_x
+        # res32_stages: the residual stream of these stages stays an fp32 tensor (no plane round trip) -- what a per-stage ev_config.mx_residual would buy
+        self.res32_stages = tuple(res32_stages)
         # exact_stages: attribution -- the convs of these generator stages evaluate their cross terms exactly (fp16 lo parts), everything else as the recipe says
         self.exact_stages = tuple(exact_stages)
         # e5m2_stages: generator stages (0-3; conv_pre / the up-conv INTO stage i count as stage i's input) whose ACTIVATION cross-term operands are E5M2
@@ -176,7 +178,7 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
         if rc.res_planes:
             fmt_i = "e5m2" if i in rc.e5m2_stages else rc.res_planes
             st = (lambda t, f=fmt_i: planes_roundtrip(t, f))
-            if rc.engine_flow and i + 1 == len(shapes.up_rates):
+            if (rc.engine_flow and i + 1 == len(shapes.up_rates)) or i in rc.res32_stages:
                 st = (lambda t: t)
         x = F.leaky_relu(x, 0.1)
         # the up-conv INTO stage i reads stage i - 1's output planes
@@ -268,6 +270,11 @@ def main():
             Recipe("ATTR r6: stage 3 exact", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", exact_stages=(3,)),
             Recipe("ATTR r6: every stage's cross terms exact (what the plane-set residual / MRF partials alone cost)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", exact_stages=(0, 1, 2, 3)),
             Recipe("ATTR r6: fp4 cross terms, fp32 residual and MRF sums (what the cross terms alone cost)", "fp4"),
+            Recipe("RES r6: ENGINE + MRF partials, fp32 residual in stage 0 only", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", res32_stages=(0,)),
+            Recipe("RES r6: fp32 residual in stage 1 only", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", res32_stages=(1,)),
+            Recipe("RES r6: fp32 residual in stage 2 only", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", res32_stages=(2,)),
+            Recipe("RES r6: fp32 residual in stages 0-2, MRF partials as planes", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", res32_stages=(0, 1, 2)),
+            Recipe("RES r6: residual from planes, fp32 MRF sums", "fp4", res_planes="fp4", engine_flow=True),
             Recipe("ATTR r6: fp32 residual / MRF, fp4 ACTIVATION codes, exact weight lo parts", "fp4", cross_w="f16"),
             Recipe("ATTR r6: fp32 residual / MRF, exact activation parts, fp4 WEIGHT codes", "fp4", cross_x="f16"),
             Recipe("ATTR r6: fp32 residual / MRF, fp4 activations, fp6 weights", "fp4", cross_w="fp6"),

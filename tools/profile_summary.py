@@ -59,7 +59,8 @@ FAMILIES = {
     # (round 4, second half: the k = 7 / 11 launches of stage 2 run on the streamed conv_gemm_mx64_kernel, the k = 3 up-conv on the persistent conv_c64_mx kernels)
     "conv_c64_mx": lambda f: [r for r in f if "conv_c64_mx" in r["Kernel_Name"] or "conv_gemm_mx64_kernel" in r["Kernel_Name"]],
     "resblock_pair_c64_mx": lambda f: [r for r in f if "resblock_pair_c64_mx" in r["Kernel_Name"]],
-    "resblock_pair_c32_mx": lambda f: [r for r in f if "resblock_pair_c32_mx" in r["Kernel_Name"]],
+    # (round 6: the k = 3 pairs of stage 3 run on resblock_pair_c32_e5_kernel -- E5M2 activation operands -- and stay in this family)
+    "resblock_pair_c32_mx": lambda f: [r for r in f if "resblock_pair_c32_mx" in r["Kernel_Name"] or "resblock_pair_c32_e5" in r["Kernel_Name"]],
     "attention_mfma_x3_lds": lambda f: [r for r in f if "attention_mfma_x3_lds_kernel" in r["Kernel_Name"]],
     "conv_post": lambda f: [r for r in f if "conv_post" in r["Kernel_Name"]],
     "mx_planes_kernel": lambda f: [r for r in f if "mx_planes_kernel" in r["Kernel_Name"]],
