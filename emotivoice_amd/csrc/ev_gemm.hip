@@ -537,6 +537,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const ConvGemmParams& p, f32x
 
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
+#ifdef EV_MXT
+        // A/B (tools/bench_mxgemm.py --dbg 4): the two epilogue waves of a SIMD (w, w + 4) end 3-5 us apart because the arbiter prefers the older one; swap their
+        // priorities half-way so that both end together and the block's slot is free earlier
+        if constexpr (SWZ) {
+            if (p.reserved0 & 4) {
+                const bool late = (threadIdx.x >> 8) != 0;          // waves 4-7
+                if (pass == 0) { if (late) __builtin_amdgcn_s_setprio(1); }
+                if (pass == NP / 2) { if (late) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+            }
+        }
+#endif
         __builtin_amdgcn_wave_barrier();
         if constexpr (LEAN) { EV_EPI_PREFETCH(pass) }
         if constexpr (SWZ) {

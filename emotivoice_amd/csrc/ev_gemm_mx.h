@@ -352,7 +352,8 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     }
 #ifdef EV_MXT
     if (p.row_seq && wave == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the wave's own stores have left for L2)
+        const unsigned long long mxt2b = __builtin_amdgcn_s_memrealtime();          // every store of the wave is issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (... and acknowledged: what s_endpgm waits for anyway)
         const unsigned long long mxt2 = __builtin_amdgcn_s_memrealtime();
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         if (lane == 0) {
             unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(p.row_seq)) + (size_t)blockIdx.x * 4;
-            o[0] = mxt0; o[1] = mxt1; o[2] = mxt2; o[3] = ((unsigned long long)xcc << 32) | hwid;
+            o[0] = mxt0; o[1] = mxt1; o[2] = mxt2; o[3] = ((unsigned long long)xcc << 48) | ((unsigned long long)(hwid & 0xffffu) << 32) | (unsigned)(mxt2 - mxt2b);
         }
     }
 #endif

@@ -126,11 +126,38 @@ def main():
                     frac = epi_c[mid] / np.maximum(res_c[mid], 1)
                     print("   resident blocks (mid 80 %% of the launch): mean %.0f | in their epilogue: mean %.0f = %.2f of the resident ones, min %.2f, max %.2f, std %.2f" %
                           (res_c[mid].mean(), epi_c[mid].mean(), frac.mean(), frac.min(), frac.max(), frac.std()))
+                    # store drain of wave 0 (last store issued -> all acknowledged) and the turnover of a CU slot: blocks grouped by CU (XCC id + HW_ID's SE / SH / CU bits),
+                    # gap = start of a block - end (wave 0, stores acknowledged) of the latest block of that CU that ended before it while the CU was full
+                    drain = (t[:, 3] & 0xffffffff).astype(np.float64) / 100.0
+                    hw = (t[:, 3] >> 32) & 0xffff
+                    xcc = (t[:, 3] >> 48) & 0xf
+                    cu = (xcc << 16) | (hw & 0xff00)          # HW_ID: [11:8] cu_id, [12] sh_id, [15:13] se_id
+                    gaps = []
+                    for c in np.unique(cu):
+                        idx = np.nonzero(cu == c)[0]
+                        st, en = np.sort(t0[idx]), np.sort(t2[idx])
+                        for k_ in range(2, len(st)):          # the k-th start on a 2-slot CU follows the (k - 2)-th end
+                            gaps.append(st[k_] - en[k_ - 2])
+                    gaps = np.array(gaps)
+                    print("   store drain of wave 0: mean %.2f us (p90 %.2f) | CU slot turnover (end of wave 0 -> next block's start): median %.2f us, mean %.2f, p10 %.2f, p90 %.2f over %d hand-overs on %d CUs" %
+                          (drain[live].mean(), np.percentile(drain[live], 90), np.median(gaps), gaps.mean(), np.percentile(gaps, 10), np.percentile(gaps, 90), len(gaps), len(np.unique(cu))))
                     # inside the epilogue (s_memtime ticks per wave): setup (bias / row-valid loads, address arithmetic), then the four 16-row passes
                     lv = live[:, None] & (te[:, :, 0] > 0)
                     dd = np.diff(te[:, :, :6], axis=2)
                     print("   epilogue per wave (s_memtime ticks): setup %.0f | passes %s | total %.0f" %
                           (dd[:, :, 0][lv].mean(), " ".join("%.0f" % dd[:, :, 1 + i][lv].mean() for i in range(4)), (te[:, :, 5] - te[:, :, 0])[lv].mean()))
+                    # skew of the waves' epilogue ends inside a block (the block's slot is free when its LAST wave ends; the turnover above is counted from wave 0's end)
+                    ends = te[:, :, 5]
+                    okb = live & (te[:, :, 0] > 0).all(axis=1)
+                    tick_us = (t2 - t1)[okb].mean() / np.maximum((te[:, 0, 5] - te[:, 0, 0])[okb].mean(), 1.0)
+                    print("   wave skew inside a block: last wave's end - first wave's end %.2f us (p90 %.2f); last wave's end - wave 0's end %.2f us" %
+                          ((ends.max(axis=1) - ends.min(axis=1))[okb].mean() * tick_us, np.percentile((ends.max(axis=1) - ends.min(axis=1))[okb], 90) * tick_us,
+                           (ends.max(axis=1) - ends[:, 0])[okb].mean() * tick_us))
+                    ent = te[:, :, 0]
+                    print("   per wave (0..7), relative to the block's first wave: epilogue entry %s us | epilogue end %s us | duration %s us" %
+                          (" ".join("%.2f" % v for v in ((ent - ent.min(axis=1, keepdims=True))[okb].mean(axis=0) * tick_us)),
+                           " ".join("%.2f" % v for v in ((ends - ends.min(axis=1, keepdims=True))[okb].mean(axis=0) * tick_us)),
+                           " ".join("%.2f" % v for v in ((ends - ent)[okb].mean(axis=0) * tick_us))))
                     # first-round skew: start times of the first 512 blocks, and block lifetimes by round
                     order = np.argsort(t0)
                     print("   starts of the first 512 blocks: %.1f .. %.1f us; epilogue length by start-time decile: %s" %
