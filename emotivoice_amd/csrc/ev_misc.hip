@@ -64,15 +64,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     if (row >= p.rows) return;
     const int nv = p.C >> 7;   // float2 chunks per lane
     const bool valid = p.row_valid ? p.row_valid[row] != 0 : true;
-    float2 v[NV];
+    float2 v[NV], gv[NV], bv[NV];
     float s = 0.f;
     const float* xr = p.x + (long)row * p.ldx;
+    // (round 6) gamma / beta requested WITH the row, not behind the two wave reductions: one exposed memory round trip per wave instead of two (same values,
+    // same arithmetic: bit-identical output)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         if (i < nv) {
             v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2);
-            s += v[i].x + v[i].y;
+            gv[i] = *reinterpret_cast<const float2*>(p.gamma + i * 128 + lane * 2);
+            bv[i] = *reinterpret_cast<const float2*>(p.beta + i * 128 + lane * 2);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (i < nv) s += v[i].x + v[i].y;
     }
     const float mean = wave_sum(s) / (float)p.C;
     float q = 0.f;
@@ -90,8 +97,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     for (int i = 0; i < NV; ++i) {
         if (i < nv) {
             const int c = i * 128 + lane * 2;
-            const float2 g = *reinterpret_cast<const float2*>(p.gamma + c);
-            const float2 b = *reinterpret_cast<const float2*>(p.beta + c);
+            const float2 g = gv[i], b = bv[i];
             float y0 = (v[i].x - mean) * rstd * g.x + b.x;
             float y1 = (v[i].y - mean) * rstd * g.y + b.y;
             if (!valid) { y0 = 0.f; y1 = 0.f; }
@@ -1228,14 +1234,26 @@ __global__ __launch_bounds__(256) void conv_post_f32_kernel(const float* __restr
     __shared__ __attribute__((aligned(16))) char xs[NROWS * PITCH];
     const int tid = threadIdx.x;
     const long r0 = (long)blockIdx.x * 256;
-    for (int c = tid; c < NROWS * CPR; c += 256) {
-        const int r = c / CPR, part = c % CPR;
-        float4 v = *reinterpret_cast<const float4*>(x + (r0 + r - HALF) * ldx + part * 4);
-        v.x = fmaxf(v.x, v.x * pre_slope); v.y = fmaxf(v.y, v.y * pre_slope); v.z = fmaxf(v.z, v.z * pre_slope); v.w = fmaxf(v.w, v.w * pre_slope);   // leaky_relu of models.py:127
-        *reinterpret_cast<float4*>(xs + r * PITCH + part * 16) = v;
+    // (round 6) ALL of a thread's requests first, then the stores: as a rolled loop (load, s_waitcnt vmcnt(0), ds_write, branch -- what hipcc made of it) a block
+    // paid nine HBM round trips one after the other, 0.28 ms for 1.08 GB; the validity byte of the thread's output row travels with them.  Same values, same
+    // summation order: bit-identical output.
+    constexpr int NIT = (NROWS * CPR + 255) / 256;
+    float4 ld[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int c = min(tid + i * 256, NROWS * CPR - 1), r = c / CPR, part = c % CPR;          // (the last, partial round re-reads the slab's last chunk)
+        ld[i] = *reinterpret_cast<const float4*>(x + (r0 + r - HALF) * ldx + part * 4);
+    }
+    const long row = r0 + tid;
+    const uint8_t vbyte = row_valid[min(row, (long)rows - 1) >> valid_shift];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int c = tid + i * 256, r = c / CPR, part = c % CPR;
+        float4 u = ld[i];
+        u.x = fmaxf(u.x, u.x * pre_slope); u.y = fmaxf(u.y, u.y * pre_slope); u.z = fmaxf(u.z, u.z * pre_slope); u.w = fmaxf(u.w, u.w * pre_slope);   // leaky_relu of models.py:127
+        if (c < NROWS * CPR) *reinterpret_cast<float4*>(xs + r * PITCH + part * 16) = u;
     }
     __syncthreads();
-    const long row = r0 + tid;
     if (row >= rows) return;
     float a = bias;
 #pragma unroll
@@ -1250,8 +1268,7 @@ __global__ __launch_bounds__(256) void conv_post_f32_kernel(const float* __restr
             a = fmaf(v.w, w[t * C + part * 4 + 3], a);
         }
     }
-    const bool valid = row_valid[row >> valid_shift] != 0;
-    wav_rows[row] = valid ? tanhf(a) : 0.f;
+    wav_rows[row] = vbyte != 0 ? tanhf(a) : 0.f;
 }
 void launch_conv_post(const void* x, int is_f32, int ldx, const float* w, float bias, int k, float pre_slope, const uint8_t* row_valid,
                       int valid_shift, float* wav_rows, int rows, int C, hipStream_t s) {
