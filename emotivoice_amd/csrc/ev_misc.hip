@@ -1115,17 +1115,34 @@ __global__ __launch_bounds__(256) void gauss_upsample_kernel(const float* xvar, 
     float2 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = make_float2(0.f, 0.f);
-    for (int j = jlo; j <= jhi; ++j) {
-        const float dd = tf - centre[off + j];
-        const float pj = expf(-1.0f * delta * (dd * dd) - mx) / sum;
-        const float* xr = xvar + (long)(off + j) * C;
+    // (round 6) four token rows requested per round trip instead of one (the loop was load -> wait -> fma per token: 9-40 serial L2 round trips per frame);
+    // the products are added in the same token order: bit-identical output
+    for (int j = jlo; j <= jhi; j += 4) {
+        float pj[4];
+        float2 xv[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = i * 128 + lane * 2;
-            if (c < C) {
-                const float2 xv = *reinterpret_cast<const float2*>(xr + c);
-                acc[i].x = fmaf(pj, xv.x, acc[i].x);
-                acc[i].y = fmaf(pj, xv.y, acc[i].y);
+        for (int u = 0; u < 4; ++u) {
+            const int jj = min(j + u, jhi);                 // (wave-uniform; a clamped row is loaded and not used)
+            const float dd = tf - centre[off + jj];
+            pj[u] = expf(-1.0f * delta * (dd * dd) - mx) / sum;
+            const float* xr = xvar + (long)(off + jj) * C;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = i * 128 + lane * 2;
+                if (c < C) xv[u][i] = *reinterpret_cast<const float2*>(xr + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j + u <= jhi) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = i * 128 + lane * 2;
+                    if (c < C) {
+                        acc[i].x = fmaf(pj[u], xv[u][i].x, acc[i].x);
+                        acc[i].y = fmaf(pj[u], xv[u][i].y, acc[i].y);
+                    }
+                }
             }
         }
     }
