@@ -416,9 +416,20 @@ static int mx_epi_variant(const ConvGemmParams& p) {
     X(EPI_RES32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RES32 | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RARE_ACT | EPI_MXP) X(EPI_GENERIC)   \
     X(EPI_RESPL | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_O32 | EPI_LEAN | EPI_MXP)                                    \
     X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN) X(EPI_RESPL | EPI_ACC32 | EPI_O32 | EPI_LEAN | EPI_MXP) X(EPI_RESPL | EPI_ACC32 | EPI_LEAN | EPI_MXP)           \
-    X(EPI_RESPL | EPI_LEAN | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_LEAN | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_LEAN | EPI_MXP)
+    X(EPI_RESPL | EPI_LEAN | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_LEAN | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_LEAN | EPI_MXP)           \
+    EV_MX_VARIANTS_NL(X)
+// (round 6 A/B, tuning builds only -- EV_MX_NOLEAN: the plane-set-residual epilogues with the NEXT pass's operands requested one pass ahead (two register sets) instead of at
+//  the top of their own pass; chosen per launch by reserved0 bit 1)
+#ifdef EV_MX_NOLEAN
+#define EV_MX_VARIANTS_NL(X) X(EPI_RESPL | EPI_MXP) X(EPI_RESPL | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_MXP | EPI_PART) X(EPI_RESPL | EPI_ACCPL | EPI_MXP)
+#else
+#define EV_MX_VARIANTS_NL(X)
+#endif
 template <int TAPS>
 static void launch_mx_taps(const ConvGemmParams& p, int e, hipStream_t s) {
+#ifdef EV_MX_NOLEAN
+    if ((p.reserved0 & 2) && (e & EPI_RESPL) && (e & EPI_MXP) && !(e & (EPI_O32 | EPI_ACC32))) e &= ~EPI_LEAN;
+#endif
     switch (e) {
 #define EV_MX_CASE(E) case (E): launch_mx_epi<TAPS, (E)>(p, s); break;
         EV_MX_VARIANTS(EV_MX_CASE)
