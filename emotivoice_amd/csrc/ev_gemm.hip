@@ -1501,49 +1501,86 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const ConvGemmP
 #pragma unroll
     for (int a = 0; a < NT; ++a) woff[a] = swz(wc * TC + a * 16 + fr, fq);
 
+    // (round 6) Prefetch distance.  With the next step's tiles requested at the top of a step and written to LDS at its bottom, a step of the token-rate GEMMs (24 MFMAs per
+    // wave, two 4-wave blocks per CU) waited for an L2 round trip every time: 1.36 us per step against 0.2 us of matrix work, MFMA-busy 0.23.  Now the WEIGHT tile of step s + 2 is
+    // requested while step s computes (a second register pair; the one written at the bottom of step s was requested during step s - 1), and the activation slab of the next
+    // K-chunk is requested at the chunk's FIRST tap instead of its last (taps >= 2; it is still written behind the last tap).  Same products in the same order: bit-identical.
+    uint4 whr2 = uint4{0u, 0u, 0u, 0u}, wlr2 = uint4{0u, 0u, 0u, 0u};
     EV_S_GLOAD_X(kc0)
     EV_S_GLOAD_W(kc0, 0)
     EV_S_SSTORE_X(0)
     EV_S_SSTORE_W(0)
     __syncthreads();
-    int kc = 0, tap = 0, wsel = 0;          // kc counts from the range's first chunk (it also picks the slab buffer); kc0 + kc is the chunk
-    for (int s = 0; s < steps; ++s) {
-        int t1 = tap + 1, k1 = kc;
-        if (t1 == taps) { t1 = 0; k1 = kc + 1; }
-        const bool has_next = s + 1 < steps;
-        const bool next_x = has_next && t1 == 0;
-        if (has_next) EV_S_GLOAD_W(kc0 + k1, t1)
-        if (next_x) EV_S_GLOAD_X(kc0 + k1)
-        {
-            const int row0 = wt * TT + fr + tap * p.dil;
-            const int xo = (kc & 1) * XBUF + row0 * 64 + ((fq ^ ((row0 >> 1) & 3)) << 4);
-            uint4 xh[MT], xl[MT], wh[NT], wl[NT];
-#pragma unroll
-            for (int b = 0; b < MT; ++b) {
-                xh[b] = *reinterpret_cast<const uint4*>(Xh + xo + b * 16 * 64);
-                xl[b] = *reinterpret_cast<const uint4*>(Xl + xo + b * 16 * 64);
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a) {
-                wh[a] = *reinterpret_cast<const uint4*>(Wh + wsel * WBUF + woff[a]);
-                wl[a] = *reinterpret_cast<const uint4*>(Wl + wsel * WBUF + woff[a]);
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-                for (int b = 0; b < MT; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wh[a]), *reinterpret_cast<half8*>(&xh[b]), acc[a][b], 0, 0, 0);
-                    accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wh[a]), *reinterpret_cast<half8*>(&xl[b]), accl[a][b], 0, 0, 0);
-                    accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wl[a]), *reinterpret_cast<half8*>(&xh[b]), accl[a][b], 0, 0, 0);
-                }
-        }
-        if (has_next) EV_S_SSTORE_W(wsel ^ 1)
-        if (next_x) EV_S_SSTORE_X(k1 & 1)
-        __syncthreads();
-        wsel ^= 1;
-        tap = t1;
-        kc = k1;
+    if (steps > 1) {                                   // W of step 1 (tap 1 of chunk 0, or tap 0 of chunk 1 for a one-tap GEMM)
+        if (taps > 1) { EV_S_GLOAD_W(kc0, 1) } else { EV_S_GLOAD_W(kc0 + 1, 0) }
     }
+    int kc = 0, tap = 0, wsel = 0;          // kc counts from the range's first chunk (it also picks the slab buffer); kc0 + kc is the chunk
+    // one step; (SH, SL): the register pair written to LDS at the bottom (W of step s + 1), (LH, LL): the pair requested at the top (W of step s + 2).
+    // STATIC = the three-tap schedule below: every request is unconditional (clamped to the range's last tile / chunk; what is written to LDS behind the last step is never
+    // read), so the body is straight-line code and hipcc keeps COUNTED vmcnt waits -- with a run-time condition around a request it falls back to vmcnt(0) at every merge.
+#define EV_S_STEP(SH, SL, LH, LL, STATIC, LOADX, STOREX)                                                                         \
+    {                                                                                                                            \
+        int t1 = tap + 1, k1 = kc;                                                                                               \
+        if (t1 == taps) { t1 = 0; k1 = kc + 1; }                                                                                 \
+        int t2 = t1 + 1, k2 = k1;                                                                                                \
+        if (t2 == taps) { t2 = 0; k2 = k1 + 1; }                                                                                 \
+        const bool has_next = s + 1 < steps;                                                                                     \
+        const bool store_x = (STATIC) ? (STOREX) : (has_next && t1 == 0);                                                        \
+        const bool load_x = (STATIC) ? (LOADX) : (taps > 1 ? (tap == 0 && kc + 1 < nkc) : has_next);                             \
+        if ((STATIC) || s + 2 < steps) {                                                                                         \
+            const bool in_ = s + 2 < steps;                                                                                      \
+            const long o_ = wsrc_off + (long)(in_ ? t2 : taps - 1) * w_tap_pitch + (long)(kc0 + (in_ ? k2 : nkc - 1)) * 64;      \
+            LH = *reinterpret_cast<const uint4*>(Whg + o_);                                                                      \
+            LL = *reinterpret_cast<const uint4*>(Wlg + o_);                                                                      \
+        }                                                                                                                        \
+        if (load_x) EV_S_GLOAD_X(kc0 + min(kc + 1, nkc - 1))                                                                     \
+        {                                                                                                                        \
+            const int row0 = wt * TT + fr + tap * p.dil;                                                                         \
+            const int xo = (kc & 1) * XBUF + row0 * 64 + ((fq ^ ((row0 >> 1) & 3)) << 4);                                        \
+            uint4 xh[MT], xl[MT], wh[NT], wl[NT];                                                                                \
+            _Pragma("unroll") for (int b = 0; b < MT; ++b) {                                                                     \
+                xh[b] = *reinterpret_cast<const uint4*>(Xh + xo + b * 16 * 64);                                                  \
+                xl[b] = *reinterpret_cast<const uint4*>(Xl + xo + b * 16 * 64);                                                  \
+            }                                                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < NT; ++a) {                                                                     \
+                wh[a] = *reinterpret_cast<const uint4*>(Wh + wsel * WBUF + woff[a]);                                             \
+                wl[a] = *reinterpret_cast<const uint4*>(Wl + wsel * WBUF + woff[a]);                                             \
+            }                                                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < NT; ++a)                                                                       \
+                _Pragma("unroll") for (int b = 0; b < MT; ++b) {                                                                 \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wh[a]), *reinterpret_cast<half8*>(&xh[b]), acc[a][b], 0, 0, 0); \
+                    accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wh[a]), *reinterpret_cast<half8*>(&xl[b]), accl[a][b], 0, 0, 0); \
+                    accl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<half8*>(&wl[a]), *reinterpret_cast<half8*>(&xh[b]), accl[a][b], 0, 0, 0); \
+                }                                                                                                                \
+        }                                                                                                                        \
+        if ((STATIC) || has_next) {                                                                                              \
+            *reinterpret_cast<uint4*>(Wh + (wsel ^ 1) * WBUF + wdst) = SH;                                                       \
+            *reinterpret_cast<uint4*>(Wl + (wsel ^ 1) * WBUF + wdst) = SL;                                                       \
+        }                                                                                                                        \
+        if (store_x) EV_S_SSTORE_X(k1 & 1)                                                                                       \
+        __syncthreads();                                                                                                         \
+        wsel ^= 1;                                                                                                               \
+        tap = t1;                                                                                                                \
+        kc = k1;                                                                                                                 \
+    }
+    if (taps == 3 && (nkc & 1) == 0) {
+        // three taps, an even number of K-chunks (every token-rate conv: K = 384 or a 384-wide split-K range): two chunks = six steps per iteration, roles static
+        for (int s = 0; s < steps; s += 6) {
+            EV_S_STEP(whr, wlr, whr2, wlr2, true, true, false)   ++s;
+            EV_S_STEP(whr2, wlr2, whr, wlr, true, false, false)  ++s;
+            EV_S_STEP(whr, wlr, whr2, wlr2, true, false, true)   ++s;
+            EV_S_STEP(whr2, wlr2, whr, wlr, true, true, false)   ++s;
+            EV_S_STEP(whr, wlr, whr2, wlr2, true, false, false)  ++s;
+            EV_S_STEP(whr2, wlr2, whr, wlr, true, false, true)   s -= 5;
+        }
+    } else {
+        for (int s = 0; s < steps; ++s) {
+            EV_S_STEP(whr, wlr, whr2, wlr2, false, false, false)
+            if (++s >= steps) break;
+            EV_S_STEP(whr2, wlr2, whr, wlr, false, false, false)
+        }
+    }
+#undef EV_S_STEP
 #undef EV_S_GLOAD_X
 #undef EV_S_SPLIT_STORE
 #undef EV_S_SSTORE_X
