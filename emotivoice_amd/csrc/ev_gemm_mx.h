@@ -137,7 +137,13 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     const int nkc16_ = p.K >> 5, nkc4 = p.K >> 7;
     const unsigned K2 = (unsigned)p.K >> 1;                // row / tap pitch of a fp4 plane in bytes; the fp16 planes' is 4 x that
     const unsigned wrp4 = K2 * TAPS;
+#ifdef EV_MX_ABL
+    // reserved0 bit 9 (abl 32): every block stages the activation rows of one of 16 tiles -- the slab requests hit L2 instead of HBM (results are garbage by design):
+    // what a launch costs when the slab round trip is short
+    const int row0 = (((p.reserved0 >> 4) & 32) ? (bid & 15) * BM : m0) - p.center * p.dil;
+#else
     const int row0 = m0 - p.center * p.dil;                // first slab row (negative for the first tile: slack rows)
+#endif
     const int row0a = row0 & ~3, soff = row0 - row0a;      // the scale run starts on a 16-byte boundary
 
     const int prow = lane >> 2;

@@ -57,7 +57,7 @@ def main():
     abl_build = "mxabl" in os.environ.get("EVHIP_LIB", "")
     names = {0: "full"}
     if abl_build:
-        names.update({1: "one-chunk main loop", 2: "no epilogue", 3: "one chunk, no epilogue", 4: "no plane stores", 8: "hi plane stored only", 16: "no scale bytes"})
+        names.update({1: "one-chunk main loop", 2: "no epilogue", 3: "one chunk, no epilogue", 4: "no plane stores", 8: "hi plane stored only", 16: "no scale bytes", 32: "slab rows from L2 (16 tiles)"})
     dbgs = [int(x) for x in args.dbg.split(",")] if args.dbg else []
     for k in [int(x) for x in args.ks.split(",")]:
         wg = (np.random.default_rng(k).standard_normal((Cc, k, Cc)) / np.sqrt(Cc * k)).astype(np.float32)

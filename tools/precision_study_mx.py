@@ -59,11 +59,40 @@ def quant_elem(v, fmt):
     return out.clamp(-vmax, vmax)
 
 
-def mx_quant(v, fmt, dim):
-    """MX block quantisation along `dim` in blocks of 32 (zero padded): shared power-of-two scale from the block max
-    (OCP MX: scale = 2^(floor(log2(amax)) - emax_elem))."""
+RULES = {"act": "ocp", "w": "ocp"}          # block-scale rule of the activation / weight quantisers (--act-rule / --w-rule)
+
+
+def mx_quant(v, fmt, dim, side="act"):
+    """MX block quantisation along `dim` in blocks of 32 (zero padded): shared power-of-two scale from the block max.
+    Rules: "ocp" = 2^(floor(log2(amax)) - emax_elem) (the OCP MX rule: a block maximum in [6, 8) x scale saturates to 6 in fp4);
+    "nosat" = 2^(floor(log2(amax x 4/3)) - emax_elem): the exponent is bumped when the maximum's mantissa is >= 1.5, nothing saturates (fp4 / fp6 only:
+    their largest value is 1.5 / 1.875 x 2^emax); "best" = whichever of the two gives the smaller squared error in the block (an offline quantiser: weights)."""
     if fmt is None:
         return v
+    rule = RULES[side]
+    if rule != "ocp" and fmt in ("fp4", "fp6"):
+        v_ = v.movedim(dim, -1)
+        n_ = v_.shape[-1]
+        pad_ = (-n_) % 32
+        vp_ = F.pad(v_, (0, pad_))
+        blk_ = vp_.reshape(*vp_.shape[:-1], -1, 32)
+        amax_ = blk_.abs().amax(-1, keepdim=True)
+        emax_ = FORMATS[fmt][2]
+        e0 = torch.floor(torch.log2(amax_.clamp_min(1e-38))) - emax_
+        e1 = torch.floor(torch.log2((amax_ * (4.0 / 3.0)).clamp_min(1e-38))) - emax_
+        outs = []
+        for e_ in (e0, e1) + ((e0 - 1, e0 + 1) if rule == "best3" else ()):
+            sc_ = torch.where(amax_ > 0, torch.exp2(e_), torch.ones_like(amax_))
+            outs.append(quant_elem(blk_ / sc_, fmt) * sc_)
+        if rule == "nosat":
+            q_ = outs[1]
+        else:
+            q_, er_ = outs[0], ((outs[0] - blk_) ** 2).sum(-1, keepdim=True)
+            for o_ in outs[1:]:
+                e2_ = ((o_ - blk_) ** 2).sum(-1, keepdim=True)
+                q_ = torch.where(e2_ < er_, o_, q_)
+                er_ = torch.minimum(e2_, er_)
+        return q_.reshape(vp_.shape)[..., :n_].movedim(-1, dim)
     v = v.movedim(dim, -1)
     n = v.shape[-1]
     pad = (-n) % 32
@@ -140,18 +169,95 @@ def conv_mx(x, w, b, rc, transposed=False, e5m2=False, exact=False, **kw):
         return y
     xl, wl = x - xh, w - wh
     kdim_w = 0 if transposed else 1      # conv_transpose weight is [Cin, Cout, k]
+    if RULES["w"] == "joint" and rc.cross == "fp4" and not exact and not getattr(rc, "cross_w", None):
+        # offline joint choice (round 6 study): the hi part of a weight may be EITHER fp16 neighbour of w -- the one whose remainder lands closer to a point of the
+        # block's fp4 grid (scale: the better of the two candidates of the 'best' rule, fixed from the round-to-nearest remainders).  The fp16 pass then multiplies
+        # that hi part, the remainder pass its code: the pair (wh', Q(w - wh')) is what approximates w.
+        RULES["w"] = "best"
+        q0 = mx_quant(wl, "fp4", kdim_w, "w")
+        # block scale actually used: recover from a re-quantisation of the block maxima is awkward; recompute per block
+        def blocks(t):
+            t_ = t.movedim(kdim_w, -1)
+            n_ = t_.shape[-1]
+            pad_ = (-n_) % 32
+            return F.pad(t_, (0, pad_)).reshape(*t_.shape[:-1], -1, 32), n_, t_.shape
+        wb, n_, shp = blocks(w)
+        whb, _, _ = blocks(wh)
+        wlb = wb - whb
+        amax_ = wlb.abs().amax(-1, keepdim=True)
+        best = None
+        for bump in (0.0, 1.0):
+            e_ = torch.floor(torch.log2((amax_ * (4.0 / 3.0 if bump else 1.0)).clamp_min(1e-38))) - 2
+            sc_ = torch.where(amax_ > 0, torch.exp2(e_), torch.ones_like(amax_))
+            # candidate hi parts: nearest, and the other fp16 neighbour on the remainder's side
+            ulp = (torch.nextafter(whb.half(), torch.full_like(whb, float("inf")).half()).float() - whb).abs()
+            ulp_dn = (whb - torch.nextafter(whb.half(), torch.full_like(whb, -float("inf")).half()).float()).abs()
+            alt = torch.where(wlb >= 0, whb + ulp, whb - ulp_dn)
+            res = []
+            for cand in (whb, alt):
+                r_ = wb - cand
+                qr = quant_elem(r_ / sc_, "fp4") * sc_
+                res.append((cand, qr, (r_ - qr).abs()))
+            pick = res[1][2] < res[0][2]
+            hi_ = torch.where(pick, res[1][0], res[0][0])
+            ql_ = torch.where(pick, res[1][1], res[0][1])
+            err_ = ((wb - hi_ - ql_) ** 2).sum(-1, keepdim=True)
+            if best is None:
+                best = [hi_, ql_, err_]
+            else:
+                use = err_ < best[2]
+                best = [torch.where(use, hi_, best[0]), torch.where(use, ql_, best[1]), torch.minimum(err_, best[2])]
+        def unblocks(tb):
+            return tb.reshape(*shp[:-1], -1)[..., :n_].movedim(-1, kdim_w)
+        wh2, wlq = unblocks(best[0]), unblocks(best[1])
+        y = op(xh, wh2, b, **kw)
+        y = y + op(mx_quant(xh, "fp4", 1), wlq, None, **kw)
+        y = y + op(mx_quant(xl, "fp4", 1), mx_quant(wh2, "fp4", kdim_w, "w"), None, **kw)
+        RULES["w"] = "joint"
+        return y
     if rc.cross == "f16" or exact:
         qa = qb = lambda t, d: r16(t)
     else:
-        qa = qb = lambda t, d: mx_quant(t, rc.cross, d)
+        qa = lambda t, d: mx_quant(t, rc.cross, d)
+        qb = lambda t, d: mx_quant(t, rc.cross, d, "w")
         if getattr(rc, "cross_x", None):
             qa = (lambda t, d: r16(t)) if rc.cross_x == "f16" else (lambda t, d: mx_quant(t, rc.cross_x, d))
         if getattr(rc, "cross_w", None):
-            qb = (lambda t, d: r16(t)) if rc.cross_w == "f16" else (lambda t, d: mx_quant(t, rc.cross_w, d))
+            qb = (lambda t, d: r16(t)) if rc.cross_w == "f16" else (lambda t, d: mx_quant(t, rc.cross_w, d, "w"))
     if e5m2:
         return y + op(e5m2_hi(xh, rc.e5m2_rne), qb(wl, kdim_w), None, **kw) + op(e5m2_lo(xl), qb(wh, kdim_w), None, **kw)
     if "xh_wl" in rc.lo_terms:
-        y = y + op(qa(xh, 1), qb(wl, kdim_w), None, **kw)
+        if RULES.get("wl_diffuse") and rc.cross == "fp4" and not getattr(rc, "cross_w", None):
+            # error diffusion along K for the codes of the weight REMAINDER (its partner xh = leaky-relu outputs has a non-zero mean over the channels, so the
+            # coherent part of sum_k xh_k err_k is mean(xh) sum_k err_k: diffusion drives sum_k err_k of a row to ~0).  Scales: the 'best' rule's.
+            wq0 = qb(wl, kdim_w)
+            wlm = wl.movedim(kdim_w, -1)
+            n_ = wlm.shape[-1]
+            pad_ = (-n_) % 32
+            wp_ = F.pad(wlm, (0, pad_))
+            blk_ = wp_.reshape(*wp_.shape[:-1], -1, 32)
+            q0_ = F.pad(wq0.movedim(kdim_w, -1), (0, pad_)).reshape(blk_.shape)
+            # recover each block's scale from the quantised block: the largest |q| is <= 6 scale; use the OCP / bumped pair and pick the one consistent with q0
+            amax_ = blk_.abs().amax(-1, keepdim=True)
+            e0 = torch.floor(torch.log2(amax_.clamp_min(1e-38))) - 2
+            sc0 = torch.where(amax_ > 0, torch.exp2(e0), torch.ones_like(amax_))
+            r0 = quant_elem(blk_ / sc0, "fp4") * sc0
+            same0 = ((r0 - q0_).abs().amax(-1, keepdim=True) == 0)
+            sc_ = torch.where(same0, sc0, sc0 * 2)
+            flat = wp_.reshape(*wp_.shape[:-1], -1)
+            scf = sc_.expand(blk_.shape).reshape(flat.shape)
+            out = torch.empty_like(flat)
+            carry = torch.zeros_like(flat[..., 0])
+            alpha = float(RULES["wl_diffuse"])
+            for k_ in range(flat.shape[-1]):
+                t_ = flat[..., k_] + alpha * carry
+                qk = quant_elem(t_ / scf[..., k_], "fp4") * scf[..., k_]
+                out[..., k_] = qk
+                carry = t_ - qk
+            wq1 = out[..., :n_].movedim(-1, kdim_w)
+            y = y + op(qa(xh, 1), wq1, None, **kw)
+        else:
+            y = y + op(qa(xh, 1), qb(wl, kdim_w), None, **kw)
     if "xl_wh" in rc.lo_terms:
         xlq = mx_quant_lo_fixed(xl, xh, rc.cross, 1) if (LO_FIXED[0] and rc.cross not in (None, "f16")) else qa(xl, 1)
         y = y + op(xlq, qb(wh, kdim_w), None, **kw)
@@ -221,9 +327,14 @@ def main():
     ap.add_argument("--weights", default="parity", help="synthetic weight recipe: parity (conv_post bias re-centred here for a zero-mean waveform) or "
                                                         "parity_zdc_hot (trained-like gains, the worst reference fixture's recipe)")
     ap.add_argument("--only", default=None, help="substring filter on the recipe names")
+    ap.add_argument("--act-rule", default="ocp", choices=("ocp", "nosat", "best"), help="block-scale rule of the activation quantisers (see mx_quant)")
+    ap.add_argument("--w-rule", default="ocp", choices=("ocp", "nosat", "best", "best3", "joint"), help="block-scale rule of the weight quantiser (offline: 'best' / 'joint' are free)")
+    ap.add_argument("--wl-diffuse", type=float, default=0.0, help="error-diffusion factor along K for the weight remainder's codes (0 = round to nearest)")
     ap.add_argument("--wseed", type=int, default=0, help="weight seed (round 6: the parity suite runs three draws of the weights)")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    RULES["act"], RULES["w"] = args.act_rule, args.w_rule
+    RULES["wl_diffuse"] = args.wl_diffuse
     shapes = EVShapes()
     sd = to_torch_sd(synth_state_dict(args.wseed, args.weights))
     utt = synth_inputs(args.seed, [args.phonemes], [7])[0]
