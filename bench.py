@@ -47,7 +47,7 @@ def mx_contract_bytes_per_frame(residual_from_planes=True, mrf_partial_planes=Tr
     """Layer-wise HBM bytes per mel frame of the generator's OWN data flow in the mx mode (not SURVEY 8(d)'s numerator: that is VOC_BYTES_PER_FRAME,
     reported as hbm_algorithmic_*).  P = 3.0625 B per element of a plane set (fp16 hi 2 + two fp4 code planes 0.5 + 0.5 + two E8M0 scales 1/32 each);
     a residual rebuilt from planes reads hi + remainder codes + their scales = 2.53125 B; stages 0-2: every conv planes in / planes out, conv2
-    + residual, the last conv of a ResBlock + the running MRF sum (fp32; stages 0-1 since round 4: a partial plane set of R bytes per element, the stage
+    + residual, the last conv of a ResBlock + the running MRF sum (stages 0-1 since round 4, stage 2 since round 6: a partial plane set of R bytes per element, the stage
     output only as the next up-conv's planes); stage 3: fused pairs, fp32 in / out (8 B per element and pair)."""
     P, R = 3.0625, 2.53125
     E, Ein = [2048, 8192, 8192, 8192], [512, 2048, 8192, 8192]       # elements per mel frame of a stage's tensors / of its up-conv's input
@@ -59,17 +59,17 @@ def mx_contract_bytes_per_frame(residual_from_planes=True, mrf_partial_planes=Tr
             continue
         b += Ein[s] * P + e * P + (0 if residual_from_planes else 4 * e)
         for j in range(3):
-            if s == 2 and j == 0 and residual_from_planes:            # the k = 3 ResBlock of stage 2: fused pairs (ev_pair64_mx.h), planes in / planes (or the fp32 MRF sum) out
-                b += 2 * (e * P + e * P) + e * P + 4 * e
+            if s == 2 and j == 0 and residual_from_planes:            # the k = 3 ResBlock of stage 2: fused pairs (ev_pair64_mx.h), planes in / planes (or the MRF sum) out
+                b += 2 * (e * P + e * P) + e * P + (e * R if mrf_partial_planes else 4 * e)
                 continue
             for d in range(3):
                 res = e * R if residual_from_planes else 4 * e
                 b += 2 * e * P + e * P + res                              # conv1 in / out, conv2 xt in + residual
                 if d < 2:
                     b += e * P + (0 if residual_from_planes else 4 * e)
-                elif mrf_partial_planes and residual_from_planes and s < 2:
-                    # stages with >= 128 channels: the running sum as a partial plane set (hi plane + remainder codes + their scales = R bytes per element),
-                    # the third ResBlock writes the next up-conv's full plane set directly
+                elif mrf_partial_planes and residual_from_planes and s < 3:
+                    # stages with >= 64 channels (stage 2 since round 6): the running sum as a partial plane set (hi plane + remainder codes + their scales =
+                    # R bytes per element), the third ResBlock writes the next up-conv's full plane set directly
                     b += (e * R if j else 0) + (e * P if j == 2 else e * R)
                 else:
                     b += (4 * e if j else 0) + 4 * e + (e * P if j == 2 else 0)     # running MRF sum in / out (or the stage output + its planes)
@@ -77,7 +77,7 @@ def mx_contract_bytes_per_frame(residual_from_planes=True, mrf_partial_planes=Tr
 
 
 # per-mode layer-wise contracts of the modes' own data flows (fp16: SURVEY 8(d); split precision: fp32 tensors; mx: the residual rebuilt
-# from planes, the fused k = 3 pairs of stage 2 and the MRF sums of stages 0-1 as partial plane sets -- the defaults since round 4; 4.310 MB with round 3's flow)
+# from planes, the fused k = 3 pairs of stage 2 and the MRF sums of stages 0-2 as partial plane sets; 4.310 MB with round 3's flow)
 VOC_BYTES_PER_FRAME_BY_MODE = {"f16": 2.026e6, "x3": 2 * 2.026e6, "mx": mx_contract_bytes_per_frame(True)}
 DEC_FLOP_PER_UTT_1024 = 40.265e9                   # mel decoder at T = 1024
 PEAK_MFMA_F16 = 2500.0                             # TFLOP/s dense (MI355X_MICROARCH.md)
@@ -349,7 +349,7 @@ def roofline_block(eng, work, torch, dump=None):
                                            hbm_contract_frac=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
                                            hbm_contract_bytes_per_frame=VOC_BYTES_PER_FRAME_BY_MODE[mode],
                                            hbm_contract_note="this mode's layer-wise byte contract (fp16: 2.026 MB / frame; split precision: fp32 tensors, 2x; "
-                                                             "mx: plane sets, residuals rebuilt from them, running MRF sums as partial plane sets in stages 0-1 and fp32 in stages 2-3, fused k = 3 pairs at C = 64: 3.24 MB / frame)"))
+                                                             "mx: plane sets, residuals rebuilt from them, running MRF sums as partial plane sets in stages 0-2 and fp32 in stage 3, fused k = 3 pairs at C = 64: 3.24 MB / frame)"))
         if voc_pmc:
             roof["all_vocoder_convs"].update(hbm_pmc_bytes_per_frame=round(voc_pmc, 1), hbm_pmc_GBps=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9, 1),
                                              hbm_pmc_frac=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),

@@ -624,8 +624,16 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         // MRF sum as partial plane sets (conv_gemm_mx_kernel stages, i.e. >= 128 channels): rb0's last conv writes out_scale * x as fp16 hi plane + fp4 remainder
         // codes, rb1's adds that to its own and rewrites it in place, rb2's adds it and writes the next up-conv's plane set: 2.53 instead of 4 bytes per element
         // and transfer (16 -> 10.1 bytes per stage-output element; tools/precision_study_mx.py: 4.17e-4 -> 4.22e-4 on the zero-mean recipe)
-        bool mrf_pl = rpl && !keep && c.mx_mrf == 0 && c.n_rb == 3 && cout % 128 == 0 && next_up_mx && vb.pl_mrf.h;
-        for (int j = 0; mrf_pl && j < c.n_rb; ++j) mrf_pl = c.rb_kernels[j] == 3 || c.rb_kernels[j] == 7 || c.rb_kernels[j] == 11;
+        // (round 6: also at C = 64 -- conv_gemm_mx64_kernel has the same epilogue variants, the fused k = 3 pair writes the partial set itself)
+        bool mrf_pl = rpl && !keep && c.mx_mrf == 0 && c.n_rb == 3 && cout % 64 == 0 && next_up_mx && vb.pl_mrf.h;
+        for (int j = 0; mrf_pl && j < c.n_rb; ++j) {
+            const int k = c.rb_kernels[j];
+            mrf_pl = k == 3 || k == 7 || k == 11;
+            // C = 64, k = 3: only the fused pair kernel writes / the streamed k = 7 / 11 kernel reads partial sets (conv_c64_mx_kernel does neither), and the pair
+            // kernel has no plane-set accumulate-in: the k = 3 ResBlock must be the first of the stage and run fused
+            if (mrf_pl && cout == 64 && k == 3)
+                mrf_pl = j == 0 && c.fused_pairs == 0 && c.rb_dils[j][c.n_rb_dils - 1] <= 8 && has_wt("voc.rb" + std::to_string(i * c.n_rb + j) + ".c2." + std::to_string(c.n_rb_dils - 1) + ".wcmx");
+        }
         U *= s;
         const int shift = ilog2(U);
         const bool last_stage = (i == c.n_up - 1);

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_mx_kernel(const ResP
     const f32x2 slope01 = f32x2{0.1f, 0.1f};
     const bool scaled = e.out_scale != 1.0f;
     const bool has_planes = e.mxo_h != nullptr;
+    const bool part_out = e.mxo_partial != 0;          // the running MRF sum as a PARTIAL plane set (hi plane + remainder codes + their scales): no hi codes / hi scales
     const f32x2 mxo_slope2 = f32x2{e.mxo_slope, e.mxo_slope};
     const bool mxo_act = e.mxo_slope != 1.0f;
     const f32x2 res_inv2 = f32x2{e.res_inv_slope, e.res_inv_slope};
@@ -372,10 +373,10 @@ __global__ __launch_bounds__(512, 1) void resblock_pair_c64_mx_kernel(const ResP
             }
             if (has_planes && rowok) {
                 *reinterpret_cast<uint4*>(reinterpret_cast<char*>(e.mxo_h) + (t * 64 + eco) * 2) = pho[it];
-                *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e.mxo_q4[0]) + t * 32 + ch * 16 + eg * 4) = pch[it];
+                if (!part_out) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e.mxo_q4[0]) + t * 32 + ch * 16 + eg * 4) = pch[it];
                 *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e.mxo_q4[1]) + t * 32 + ch * 16 + eg * 4) = pcl[it];
                 if (eg == 0) {
-                    reinterpret_cast<uint8_t*>(e.mxo_qs[0])[t * 4 + ch] = (uint8_t)pbh[it];
+                    if (!part_out) reinterpret_cast<uint8_t*>(e.mxo_qs[0])[t * 4 + ch] = (uint8_t)pbh[it];
                     reinterpret_cast<uint8_t*>(e.mxo_qs[1])[t * 4 + ch] = (uint8_t)pbl[it];
                 }
             }
@@ -400,13 +401,15 @@ static hipError_t pair64_mx_set_attributes() {
 }
 // x = the input plane set's fp16 hi plane [rows][64] (ldx == 64), epi.mx_x4 / mx_xs its code / scale planes ([rows][32 B] / [rows][4]); w1 / w2 fp16 hi
 // parts [64][3][64], w1_mx / w2_mx = mxfp4.pack_c64_weight_planes; epi: bias (= b2), res_inv_slope (the residual IS the input plane set), out_scale, acc32
-// (optional, may alias out32), row_valid, outputs out32 (ldo == 64) and / or the plane set mxo_* (mxo_logC == 6).  0, or -1 for an unsupported call.
+// (optional, may alias out32), row_valid, outputs out32 (ldo == 64) and / or the plane set mxo_* (mxo_logC == 6; mxo_partial: the MRF sum's partial plane set --
+// hi plane, remainder codes and their scales of the raw scaled result, planes only).  0, or -1 for an unsupported call.
 int launch_resblock_pair_c64_mx(const ResPairParams& p, hipStream_t s) {
     const ConvGemmParams& e = p.epi;
     if (p.k != 3 || p.ldx != 64 || p.dil < 1 || p.dil > Pair64MxGeom::MAXDIL || p.M <= 0 || !p.w1_mx || !p.w2_mx || !e.mx_x4[0] || !e.mx_x4[1] || !e.mx_xs[0] || !e.mx_xs[1] ||
         !(e.out32 || e.mxo_h) || e.out16 || e.add16_a || e.post_lrelu || e.seq_bias || e.out32_before_post || !(e.res_inv_slope >= 1.0f) ||
         (e.out32 && e.ldo != 64) || (e.acc32 && e.ldacc != 64) ||
-        (e.mxo_h && !(e.mxo_logC == 6 && e.mxo_q4[0] && e.mxo_q4[1] && e.mxo_qs[0] && e.mxo_qs[1] && e.mxo_slope >= 0.f && e.mxo_slope <= 1.f)))
+        (e.mxo_h && !(e.mxo_logC == 6 && (e.mxo_partial || (e.mxo_q4[0] && e.mxo_qs[0])) && e.mxo_q4[1] && e.mxo_qs[1] && e.mxo_slope >= 0.f && e.mxo_slope <= 1.f)) ||
+        (e.mxo_partial && !(e.mxo_h && e.mxo_slope == 1.0f && !e.out32)) || e.acc_h)
         return -1;
     const int n_cu = device_cus();
     const int ntiles = (p.M + Pair64MxGeom::BMO - 1) / Pair64MxGeom::BMO;

@@ -1314,6 +1314,58 @@ def test_fused_mx_resblock_pair_c64(lib, dil, mode, M):
     assert lib.ev_op_resblock_pair_c64_mx(C.byref(dp), None) == -2          # only k = 3 is built
 
 
+@pytest.mark.parametrize("dil,M", [(5, 256 * 3), (1, 256 * 2)])
+def test_fused_mx_resblock_pair_c64_partial_out(lib, dil, M):
+    """The fused C = 64 pair writing the stage's running MRF sum as a PARTIAL plane set (mxo_partial: hi plane, remainder codes, remainder scales of the raw
+    scaled result -- round 6, stage 2): the same bits as the hi / remainder planes of the full plane set at slope 1, hi codes and hi scales left alone."""
+    from emotivoice_amd import _ffi, mxfp4
+    torch.manual_seed(6400 + dil + M)
+    Cc, k = 64, 3
+    R = M + 2 * PAD
+    valid = torch.ones(M // 8, dtype=torch.uint8, device="cuda")
+    valid[:1] = 0
+    valid[-3:] = 0
+    x = torch.randn(R, Cc) * torch.exp(0.5 * torch.randn(R, 1))
+    x[:PAD] = 0
+    x[PAD + M:] = 0
+    x[PAD:PAD + M][~valid.repeat_interleave(8).bool().cpu()] = 0
+    ps_x, _ = _host_plane_set(_lrelu(x, 0.1).float())
+
+    def wset(seed):
+        g = torch.Generator().manual_seed(seed)
+        wg = (torch.randn(Cc, k, Cc, generator=g) / math.sqrt(Cc * k)).numpy()
+        return torch.from_numpy(wg.astype(np.float16)).cuda(), torch.from_numpy(mxfp4.pack_c64_weight_planes(wg)).cuda()
+    w1h, w1m = wset(11)
+    w2h, w2m = wset(12)
+    b1, b2 = torch.randn(Cc, device="cuda") * 0.1, torch.randn(Cc, device="cuda") * 0.1
+    sets = []
+    for part in (0, 1):
+        ps_o = _PlaneSet(M, Cc)
+        dp = _ffi.ev_res_pair_desc()
+        dp.x, dp.ldx, dp.w1, dp.b1, dp.w2, dp.M, dp.k, dp.dil = ps_x.h[PAD:].data_ptr(), Cc, w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), M, k, dil
+        dp.w1_mx, dp.w2_mx = w1m.data_ptr(), w2m.data_ptr()
+        e = dp.epi
+        e.mx_x4[0], e.mx_x4[1] = ps_x.q4[0][PAD:].data_ptr(), ps_x.q4[1][PAD:].data_ptr()
+        e.mx_xs[0], e.mx_xs[1], e.mx_xs_stride = ps_x.qs[0][0, PAD:].data_ptr(), ps_x.qs[1][0, PAD:].data_ptr(), R * 4
+        e.bias, e.row_valid, e.valid_shift, e.out_scale, e.ldo, e.res_inv_slope = b2.data_ptr(), valid.data_ptr(), 3, 1.0 / 3.0, Cc, 10.0
+        ps_o.out_fields(e, 1.0)
+        e.mxo_logC, e.mxo_partial = 6, part
+        torch.cuda.synchronize()
+        assert lib.ev_op_resblock_pair_c64_mx(C.byref(dp), None) == 0
+        torch.cuda.synchronize()
+        sets.append(ps_o)
+        if part:          # a partial set beside an fp32 output, or with an activation, is not a call the kernel takes
+            e.mxo_slope = 0.1
+            assert lib.ev_op_resblock_pair_c64_mx(C.byref(dp), None) != 0
+    full, part = sets
+    assert float(full.h[PAD:PAD + M].float().abs().max()) > 0.1
+    assert torch.equal(full.h[PAD:PAD + M], part.h[PAD:PAD + M])
+    assert torch.equal(full.q4[1][PAD:PAD + M], part.q4[1][PAD:PAD + M])
+    assert torch.equal(full.qs[1][0, PAD:PAD + M, :2], part.qs[1][0, PAD:PAD + M, :2])
+    assert bool((part.q4[0] == 0x77).all()) and bool((part.qs[0] == 130).all())          # hi codes / hi scales untouched
+    assert not bool((full.q4[0][PAD:PAD + M] == 0x77).all())
+
+
 @pytest.mark.parametrize("k,dil,mode,M", [(3, 1, "conv1", 256 * 3), (3, 5, "conv2acc", 256 * 8), (7, 3, "conv1", 256 * 9), (7, 1, "conv2", 256 * 17),
                                           (11, 5, "conv1", 256 * 8), (11, 1, "conv2acc", 256 * 5), (3, 1, "up", 256 * 8)])
 def test_conv_c64_mx(lib, k, dil, mode, M):

@@ -126,7 +126,12 @@ LO_FIXED = [False]          # set per recipe by emulate()
 
 class Recipe:
     def __init__(self, name, cross=None, res32=True, op32=True, hi_from="f16", lo_terms=("xh_wl", "xl_wh"), res_planes=None, mrf16=False,
-                 engine_flow=False, mrf_planes=None, lo_fixed=False, e5m2_stages=(), e5m2_rne=False, exact_stages=(), cross_w=None, cross_x=None, res32_stages=()):
+                 engine_flow=False, mrf_planes=None, lo_fixed=False, e5m2_stages=(), e5m2_rne=False, exact_stages=(), cross_w=None, cross_x=None, res32_stages=(),
+                 nocross_stages=(), only_term_stages=None):
+        # nocross_stages: the convs of these stages drop BOTH cross terms (one fp16 MFMA per product, fp32 storage as the recipe says) -- what a stage costs in
+        # accuracy when it runs the fast mode's arithmetic on the mx mode's data flow; only_term_stages = (stages, term): keep only that cross term there
+        self.nocross_stages = tuple(nocross_stages)
+        self.only_term_stages = only_term_stages
         # cross_w / cross_x: attribution -- override the format of the WEIGHT / ACTIVATION side of the cross terms ("f16" = exact lo parts)
         self.cross_w, self.cross_x = cross_w, cross_x
         # res32_stages: the residual stream of these stages stays an fp32 tensor (no plane round trip) -- what a per-stage ev_config.mx_residual would buy
@@ -160,12 +165,12 @@ def planes_roundtrip(x, fmt):
     return torch.where(a2 >= 0, a2, a2 * 10.0)
 
 
-def conv_mx(x, w, b, rc, transposed=False, e5m2=False, exact=False, **kw):
+def conv_mx(x, w, b, rc, transposed=False, e5m2=False, exact=False, kw_nocross=False, only_term=None, **kw):
     """x [1, C, T] fp32, w fp32.  hi.hi in fp16 operands + cross terms in rc.cross (None = omitted, 'f16' = fp16 exact)."""
     op = F.conv_transpose1d if transposed else F.conv1d
     xh, wh = r16(x), r16(w)
     y = op(xh, wh, b, **kw)
-    if rc.cross is None:
+    if rc.cross is None or kw_nocross:
         return y
     xl, wl = x - xh, w - wh
     kdim_w = 0 if transposed else 1      # conv_transpose weight is [Cin, Cout, k]
@@ -226,7 +231,8 @@ def conv_mx(x, w, b, rc, transposed=False, e5m2=False, exact=False, **kw):
             qb = (lambda t, d: r16(t)) if rc.cross_w == "f16" else (lambda t, d: mx_quant(t, rc.cross_w, d, "w"))
     if e5m2:
         return y + op(e5m2_hi(xh, rc.e5m2_rne), qb(wl, kdim_w), None, **kw) + op(e5m2_lo(xl), qb(wh, kdim_w), None, **kw)
-    if "xh_wl" in rc.lo_terms:
+    lo_terms = rc.lo_terms if only_term is None else (only_term,)
+    if "xh_wl" in lo_terms:
         if RULES.get("wl_diffuse") and rc.cross == "fp4" and not getattr(rc, "cross_w", None):
             # error diffusion along K for the codes of the weight REMAINDER (its partner xh = leaky-relu outputs has a non-zero mean over the channels, so the
             # coherent part of sum_k xh_k err_k is mean(xh) sum_k err_k: diffusion drives sum_k err_k of a row to ~0).  Scales: the 'best' rule's.
@@ -258,7 +264,7 @@ def conv_mx(x, w, b, rc, transposed=False, e5m2=False, exact=False, **kw):
             y = y + op(qa(xh, 1), wq1, None, **kw)
         else:
             y = y + op(qa(xh, 1), qb(wl, kdim_w), None, **kw)
-    if "xl_wh" in rc.lo_terms:
+    if "xl_wh" in lo_terms:
         xlq = mx_quant_lo_fixed(xl, xh, rc.cross, 1) if (LO_FIXED[0] and rc.cross not in (None, "f16")) else qa(xl, 1)
         y = y + op(xlq, qb(wh, kdim_w), None, **kw)
     return y
@@ -274,7 +280,9 @@ def emulate(sd, mel_ct, shapes, rc, prefix="generator"):
     stage = [0]
 
     def conv(x, name, **kw):
-        return conv_mx(x, fold_weight_norm(sd, name), sd[name + ".bias"], rc, e5m2=stage[0] in rc.e5m2_stages, exact=stage[0] in rc.exact_stages, **kw)
+        ot = rc.only_term_stages[1] if (rc.only_term_stages and stage[0] in rc.only_term_stages[0]) else None
+        return conv_mx(x, fold_weight_norm(sd, name), sd[name + ".bias"], rc, e5m2=stage[0] in rc.e5m2_stages, exact=stage[0] in rc.exact_stages,
+                       kw_nocross=stage[0] in rc.nocross_stages, only_term=ot, **kw)
 
     x = mel_ct.unsqueeze(0)
     x = st(conv(x, prefix + ".conv_pre", padding=3))
@@ -389,6 +397,10 @@ def main():
             Recipe("ATTR r6: fp32 residual / MRF, fp4 ACTIVATION codes, exact weight lo parts", "fp4", cross_w="f16"),
             Recipe("ATTR r6: fp32 residual / MRF, exact activation parts, fp4 WEIGHT codes", "fp4", cross_x="f16"),
             Recipe("ATTR r6: fp32 residual / MRF, fp4 activations, fp6 weights", "fp4", cross_w="fp6"),
+            Recipe("FAST3 r6: ENGINE + MRF partials, stage 3 without cross terms (fp16 operands, fp32 rows)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", nocross_stages=(3,)),
+            Recipe("FAST3 r6: stage 3 with the weight correction only (xh.wl)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", only_term_stages=((3,), "xh_wl")),
+            Recipe("FAST3 r6: stage 3 with the operand correction only (xl.wh)", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", only_term_stages=((3,), "xl_wh")),
+            Recipe("FAST3 r6: stages 2 + 3 without cross terms", "fp4", res_planes="fp4", engine_flow=True, mrf_planes="fp4", nocross_stages=(2, 3)),
             Recipe("+ MX-fp4, only xh.wl (weight correction)", "fp4", lo_terms=("xh_wl",)),
             Recipe("+ MX-fp4, only xl.wh (operand correction)", "fp4", lo_terms=("xl_wh",)),
         ]
