@@ -349,7 +349,7 @@ def roofline_block(eng, work, torch, dump=None):
                                            hbm_contract_frac=round(VOC_BYTES_PER_FRAME_BY_MODE[mode] * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
                                            hbm_contract_bytes_per_frame=VOC_BYTES_PER_FRAME_BY_MODE[mode],
                                            hbm_contract_note="this mode's layer-wise byte contract (fp16: 2.026 MB / frame; split precision: fp32 tensors, 2x; "
-                                                             "mx: plane sets, residuals rebuilt from them, running MRF sums as partial plane sets in stages 0-2 and fp32 in stage 3, fused k = 3 pairs at C = 64: 3.24 MB / frame)"))
+                                                             "mx: plane sets, residuals rebuilt from them, running MRF sums as partial plane sets in stages 0-2 and fp32 in stage 3, fused k = 3 pairs at C = 64: 3.16 MB / frame)"))
         if voc_pmc:
             roof["all_vocoder_convs"].update(hbm_pmc_bytes_per_frame=round(voc_pmc, 1), hbm_pmc_GBps=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9, 1),
                                              hbm_pmc_frac=round(voc_pmc * f1 / (voc_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
