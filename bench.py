@@ -215,6 +215,46 @@ class Workload:
         return frames
 
 
+def power_sample(work, torch, seconds=2.5):
+    """Clock and socket power while the workload loops (rocm-smi polled from a thread; the readings lag the load by a few hundred ms, so the first 0.7 s are
+    dropped).  Outside the timed region.  None when rocm-smi is not there.  Round 6 finding (profiles/r6_j_*): every kernel family of the generator runs AT the
+    1400 W board limit, at 1.63-2.03 GHz instead of 2.4 -- the roofs quoted against the nominal clock have a ceiling of 0.68-0.85 under this load."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    import time
+    if not shutil.which("rocm-smi"):
+        return None
+    samples, stop = [], [False]
+
+    def poll():
+        while not stop[0]:
+            t = time.perf_counter()
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            m1, m2 = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out), re.search(r"Power \(W\): ([\d.]+)", out)
+            if m1 and m2:
+                samples.append((t, int(m1.group(1)), float(m2.group(1))))
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        work.step()
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    stop[0] = True
+    th.join(timeout=6)
+    mine = [x for x in samples if t0 + 0.7 < x[0] < t1 - 0.05]
+    if len(mine) < 3:
+        return None
+    return dict(sclk_MHz=int(np.median([x[1] for x in mine])), socket_W=round(float(np.median([x[2] for x in mine])), 0), samples=len(mine), nominal_sclk_MHz=2400,
+                note="rocm-smi polled while the workload loops for %.1f s outside the timed region; board limit 1400 W" % seconds)
+
+
 def b1_latency(eng, phonemes=(64, 256)):
     """Single-utterance latency (the reference's own call pattern, B = 1; BASELINE configs[0] is 64 phonemes): host-to-host wall time of one
     ev_synthesize with host inputs, best of 20.  Measured BEFORE the throughput loop: right after it the chip still runs at its sustained-load
@@ -607,6 +647,7 @@ def main():
         torch.cuda.synchronize()
 
     frames, dt = timed(work, args.steps, args.warmup, sync)
+    power = power_sample(work, torch) if (rank == 0 and world == 1) else None
     ranks_seen = [0]
     per_rank = [dict(rank=0, frames=int(frames), s=round(dt, 6))]
     if dist is not None:
@@ -658,6 +699,12 @@ def main():
         "latency": lat, "roofline": roof, "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "kernels_ms": kernels,
         "other_precision": other,
     }
+    if power and roof:
+        clk = power["sclk_MHz"] / 2400.0
+        line["power"] = power
+        roof["frac_at_measured_clock"] = round(roof["frac"] / clk, 4)
+        roof["measured_clock_note"] = ("the forward runs power-limited: sclk %d MHz at %d W under load (line.power); frac_at_measured_clock = frac x 2400 / sclk -- "
+                                       "what the dominant family reaches of its arithmetic's roof at the clock the chip actually sustains" % (power["sclk_MHz"], int(power["socket_W"])))
     if world == 1 and args.cpu_utts > 0:
         line["cpu_baseline"] = cpu_baseline(args.cpu_utts, args.phonemes, args.cpu_threads)
     else:

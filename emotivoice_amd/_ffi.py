@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVHIP_LIB", os.path.join(_HERE, "csrc", "libevhip.so"))
-EV_ABI_VERSION = 6
+EV_ABI_VERSION = 7
 EV_PREC_F16, EV_PREC_F32, EV_PREC_X3, EV_PREC_MX = 0, 1, 2, 3
 EV_FLAG_DEVICE_INPUTS, EV_FLAG_NO_VOCODER, EV_FLAG_WANT_INT16, EV_FLAG_FORCED_DURATIONS = 1, 2, 4, 8
 
@@ -28,6 +28,7 @@ class ev_config(C.Structure):
         ("token_rate_split", C.c_int32), ("vocoder_chunk_mb", C.c_int32), ("vocoder_streams", C.c_int32),
         ("vocoder_precision", C.c_int32), ("mx_residual", C.c_int32), ("decoder_attention", C.c_int32),
         ("fused_pairs", C.c_int32), ("mx_mrf", C.c_int32), ("decoder_ln_planes", C.c_int32), ("token_splitk", C.c_int32), ("mx_act_format", C.c_int32),
+        ("mx_group", C.c_int32),
     ]
 
 

@@ -330,6 +330,26 @@ int gemm(ev_handle* h, const char* name, const ConvGemmParams& p, double valid_r
     launch_conv_gemm(p, st ? st : h->stream);
     return 0;
 }
+// three independent convs of one level of a stage's ResBlocks as one grid (launch_conv_gemm_group3), or one by one when they are not such a triple
+int gemm_group3(ev_handle* h, const char* name, const ConvGemmParams* ps, double valid_rows) {
+    double flops = 0, bytes = 0;
+    int taps = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (check_gemm(h, ps[i])) return -1;
+        flops += 2.0 * valid_rows * ps[i].N * (double)ps[i].K * ps[i].taps;
+        bytes += valid_rows * ((double)ps[i].K * 4 + (double)ps[i].N * (ps[i].out32 ? 4 : 0)) + (double)ps[i].N * ps[i].K * ps[i].taps * 4;
+        taps += ps[i].taps;
+    }
+    if (launch_conv_gemm_group3(ps, h->stream, true) == 0) {
+        ConvGemmParams shape = ps[0];
+        shape.taps = taps; shape.dil = 0;          // (the record of a grouped launch: the three convs' taps summed, no single dilation)
+        KScope ks(h, name, flops, bytes, nullptr, &shape);
+        return launch_conv_gemm_group3(ps, h->stream);
+    }
+    for (int i = 0; i < 3; ++i)          // not a triple the grouped kernel takes: one by one
+        if (gemm(h, name, ps[i], valid_rows)) return -1;
+    return 0;
+}
 ConvGemmParams gemm_defaults() {
     ConvGemmParams p;
     memset(&p, 0, sizeof p);
@@ -674,6 +694,17 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         // accumulator shared by the three ResBlocks, so they run in order on the handle's stream.)
         const bool conc = c.n_rb == 3 && nchunks == 1 && (!x3 || (mx && !keep && voc_small_batch(Rf))) && !h->profiling && c.vocoder_streams != 1 &&
                           h->aux[0] && h->aux[1];
+        // Large batches on the conv_gemm_mx_kernel stages (round 6, ev_config.mx_group == 0): the three ResBlocks advance level by level -- the three conv1 of a
+        // pair position, then the three conv2 -- each level ONE grouped launch (launch_conv_gemm_group3: a launch of its own costs every conv 30-50 us of ramp and
+        // tail); the last conv2 of each ResBlock stays a launch of its own (the running MRF sum orders them).  Each ResBlock has its own intermediates; descriptors
+        // are built in the usual ResBlock order and issued level by level.  Same kernels' code on the same data: the same bits.
+        bool grp = stage_mx && rpl && !keep && !conc && nchunks == 1 && c.mx_group == 0 && c.n_rb == 3 && cout % 128 == 0 && vb.pl_t[2].h && vb.pl_a[2].h && vb.pl_b[2].h;
+        {
+            int seen = 0;
+            for (int j = 0; j < c.n_rb; ++j) seen |= c.rb_kernels[j] == 3 ? 1 : (c.rb_kernels[j] == 7 ? 2 : (c.rb_kernels[j] == 11 ? 4 : 8));
+            if (seen != 7) grp = false;
+        }
+        std::vector<ConvGemmParams> pend(grp ? (size_t)c.n_rb * 2 * c.n_rb_dils : 0);
         if (conc) {
             (void)hipEventRecord(h->ev_fork, h->stream);
             (void)hipStreamWaitEvent(h->aux[0], h->ev_fork, 0);
@@ -686,7 +717,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
             const int k = c.rb_kernels[j];
             const std::string rb = "voc.rb" + std::to_string(i * c.n_rb + j);
             const void* xcur = vb.xu[i].p;
-            const int bj = conc ? j : 0;
+            const int bj = (conc || grp) ? j : 0;
             hipStream_t sj = (conc && j < 2) ? h->aux[j] : h->stream;
             for (int d = 0; d < c.n_rb_dils; ++d) {
                 const int dil = c.rb_dils[j][d];
@@ -710,7 +741,8 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     p.M = rows_out; p.N = cout; p.K = cout; p.taps = k; p.dil = dil; p.center = (k - 1) / 2;
                     p.row_valid = h->d_frm_valid; p.valid_shift = shift; p.act = ACT_LRELU; p.act_slope = 0.1f; p.ldo = cout;
                     mx_out(p, mx_view(vb.pl_t[bj], (size_t)rows_out, cout), 1.0f);
-                    if (gemm(h, cout == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx", p, valid_out, sj)) return -1;
+                    if (grp) pend[((size_t)j * c.n_rb_dils + d) * 2] = p;
+                    else if (gemm(h, cout == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx", p, valid_out, sj)) return -1;
                 } else if (!fused) {
                     // xt = lrelu(c1(lrelu(x)))  (models.py:51-53)
                     p = gemm_defaults();
@@ -813,9 +845,22 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
                     KScope ks(h, cout == 32 ? "voc_resblock_pair_c32" : "voc_resblock_pair_c64", fl, valid_out * frac * cout * 2.0 * 2.0, sj, &shape);
                     if (cout == 32) launch_resblock_pair_c32(rp, sj);
                     else launch_resblock_pair_c64(rp, sj);
-                } else if (gemm(h, p.dtype == DT_MX ? (cout == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx") : gname, p, valid_out * frac, sj)) return -1;
+                } else if (grp) pend[((size_t)j * c.n_rb_dils + d) * 2 + 1] = p;
+                else if (gemm(h, p.dtype == DT_MX ? (cout == 64 ? "voc_conv_c64_mx" : "voc_conv_gemm_mx") : gname, p, valid_out * frac, sj)) return -1;
             }
             if (conc && j < 2) (void)hipEventRecord(h->ev_join[j], h->aux[j]);
+        }
+        if (grp) {
+            for (int lvl = 0; lvl < 2 * c.n_rb_dils; ++lvl) {
+                ConvGemmParams ps[3];
+                for (int j = 0; j < 3; ++j) ps[j] = pend[((size_t)j * c.n_rb_dils) * 2 + lvl];
+                if (lvl + 1 < 2 * c.n_rb_dils) {
+                    if (gemm_group3(h, "voc_conv_gemm_mx", ps, valid_out)) return -1;
+                } else {
+                    for (int j = 0; j < 3; ++j)
+                        if (gemm(h, "voc_conv_gemm_mx", ps[j], valid_out)) return -1;
+                }
+            }
         }
         }   // row chunks
         prev = vb.nxt[i].p;
@@ -879,7 +924,9 @@ void plan_vocoder(ArenaPlan& ap, const ev_config& c, int Rf, bool keep, VocBufs&
             hb = std::max(hb, R * ch * 2); qb = std::max(qb, R * (ch / 2)); sb = std::max(sb, (size_t)std::max(1, ch / 128) * R * 4);
         }
         std::vector<PlaneBuf*> sets = {&vb.pl_xu, &vb.pl_nxt, &vb.pl_mrf};
-        for (int j = 0; j < (per_rb ? 3 : 1); ++j) { sets.push_back(&vb.pl_t[j]); sets.push_back(&vb.pl_a[j]); sets.push_back(&vb.pl_b[j]); }
+        // (one set of intermediates per ResBlock also for large batches when their same-level convs are launched grouped: ev_config.mx_group == 0)
+        const bool per_rb_planes = per_rb || (c.n_rb == 3 && !keep && c.mx_group == 0 && c.mx_residual == 0);
+        for (int j = 0; j < (per_rb_planes ? 3 : 1); ++j) { sets.push_back(&vb.pl_t[j]); sets.push_back(&vb.pl_a[j]); sets.push_back(&vb.pl_b[j]); }
         for (PlaneBuf* b : sets) {
             if (!hb) break;
             b->h = ap.take(hb);
@@ -1012,8 +1059,8 @@ int ev_create(int device_id, const ev_config* cfg, ev_handle** out) {
         return fail(nullptr, "ev_create: unknown decoder_precision %d", cfg->decoder_precision);
     if (cfg->vocoder_precision != EV_PREC_F16 && cfg->vocoder_precision != EV_PREC_X3 && cfg->vocoder_precision != EV_PREC_MX)
         return fail(nullptr, "ev_create: vocoder_precision must be EV_PREC_F16, EV_PREC_X3 or EV_PREC_MX");
-    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs | cfg->mx_mrf | cfg->decoder_ln_planes | cfg->token_splitk | cfg->mx_act_format) & ~1)
-        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs / mx_mrf / decoder_ln_planes / token_splitk / mx_act_format must be 0 or 1");
+    if ((cfg->mx_residual | cfg->decoder_attention | cfg->fused_pairs | cfg->mx_mrf | cfg->decoder_ln_planes | cfg->token_splitk | cfg->mx_act_format | cfg->mx_group) & ~1)
+        return fail(nullptr, "ev_create: mx_residual / decoder_attention / fused_pairs / mx_mrf / decoder_ln_planes / token_splitk / mx_act_format / mx_group must be 0 or 1");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "ev_create: no HIP device available (%s) -- the product path has no CPU fallback", hipGetErrorString(e));

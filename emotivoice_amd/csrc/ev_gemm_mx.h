@@ -100,8 +100,10 @@ __device__ __forceinline__ void mfma_mx_inplace(f32x4& c, const uint4& a, const 
 // [22 KB, 24 KB): weight scales [tap][128]
 static constexpr int MX_XS_OFF = 20480, MX_WS_OFF = 22528;
 
+// One 256-row x 128-channel tile of a launch.  bid_in / nblk: the block's index among the launch's (or, in a grouped launch, the problem's) blocks and their
+// number; a grouped launch pads every problem to a multiple of eight blocks so that bid_in & 7 is the XCD the hardware's round-robin gave the block.
 template <int TAPS, int EPI>
-__global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmParams p) {
+__device__ __forceinline__ void conv_gemm_mx_tile(const ConvGemmParams& p, const int bid_in, const int nblk) {
     constexpr int BM = PH_BM, XBUF = PH_XBUF, WBUF = PH_WBUF, U = TAPS, TC = 64, MT = 4, NT = 4;
     static_assert(U >= 3 && TAPS * 128 <= 2048 && PH_SLABR >= BM + MAX_SPAN + 64, "pipeline depth / scale pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,12 +129,13 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     // in one process against one block per tile (profiles/r4_b_mx_persistent_ab.txt): 0-5 % SLOWER on every stage-0 / stage-1 shape.  The hardware's
     // own dispatch back-fills a CU the moment a block retires; a static stride cannot, and the loop needs a block barrier per tile because the
     // epilogue's transposing scratch aliases the staging buffers.  The fixed cost is pipeline fill latency, not block launch.)
-    int bid = blockIdx.x;
-    const int nblk = gridDim.x, nN = p.N >> 7;
+    int bid = bid_in;
+    const int nN = p.N >> 7;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
+    if (bid >= (p.M / BM) * nN) return;          // (padding blocks of a grouped launch; never true for a launch of its own)
     const int m0 = (bid / nN) * BM, nt = bid % nN, n0 = nt * 128;
     const int nkc16_ = p.K >> 5, nkc4 = p.K >> 7;
     const unsigned K2 = (unsigned)p.K >> 1;                // row / tap pitch of a fp4 plane in bytes; the fp16 planes' is 4 x that
@@ -373,6 +376,27 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
 #endif
 }
 
+template <int TAPS, int EPI>
+__global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmParams p) {
+    conv_gemm_mx_tile<TAPS, EPI>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Grouped launch (round 6): the same-level convs of a stage's three ResBlocks (k = 11, 7, 3; same M, N, K, same epilogue form) are independent, and a launch of its
+// own costs each of them 30-50 us of ramp + tail (tools/bench_mxgemm.py: 2 x T(M / 2) - T(M)).  One grid carries the three problems' tiles back to back, longest
+// tiles first: a CU that runs out of k = 11 tiles continues with k = 7 tiles, and the launch ends on the short k = 3 tiles.  Every tile runs the code of its own
+// instantiation on its own problem: the results are those of the three launches, bit for bit.
+struct ConvGemmGroup3 {
+    ConvGemmParams p[3];          // taps 11, 7, 3
+    int n0, n01;                  // blocks of problem 0, of problems 0 + 1 (each problem padded to a multiple of 8 blocks)
+};
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void conv_gemm_mx_group3_kernel(const ConvGemmGroup3 g) {
+    const int b = (int)blockIdx.x;
+    if (b < g.n0) conv_gemm_mx_tile<11, EPI>(g.p[0], b, g.n0);
+    else if (b < g.n01) conv_gemm_mx_tile<7, EPI>(g.p[1], b - g.n0, g.n01 - g.n0);
+    else conv_gemm_mx_tile<3, EPI>(g.p[2], b - g.n01, (int)gridDim.x - g.n01);
+}
+
 #include "ev_gemm_mx1.h"
 
 template <int TAPS, int EPI>
@@ -457,6 +481,8 @@ static hipError_t mx_set_attributes() {
     r = mx_attr_taps<7>(); if (r != hipSuccess) e = r;
     r = mx_attr_taps<11>(); if (r != hipSuccess) e = r;
     r = mx1_set_attributes(); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_mx_group3_kernel<EPI_MXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_mx_group3_kernel<EPI_RESPL | EPI_LEAN | EPI_MXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
     return e;
 }
 
@@ -515,4 +541,31 @@ static void launch_mx(const ConvGemmParams& p_in, hipStream_t s) {
         case 7: launch_mx_taps<7>(p, e, s); break;
         default: launch_mx_taps<11>(p, e, s); break;
     }
+}
+
+// Grouped launch of three independent DT_MX convs (see conv_gemm_mx_group3_kernel): plane sets in, the same M / N / K and epilogue form (conv1 of a ResBlock pair:
+// planes only; conv2 inside a ResBlock: residual from planes, planes only), taps {3, 7, 11} in any order.  0 = launched as one grid; -1 = not such a triple
+// (the caller launches them one by one).  Same bits either way.
+int launch_conv_gemm_group3(const ConvGemmParams* ps, hipStream_t s, bool check_only) {
+    int order[3] = {-1, -1, -1};          // problem with 11, 7, 3 taps
+    for (int i = 0; i < 3; ++i) {
+        const ConvGemmParams& p = ps[i];
+        if (p.dtype != DT_MX || p.taps == 1 || !mx_planes_in(p) || !mx_eligible(p) || p.reserved0) return -1;
+        if (p.M != ps[0].M || p.N != ps[0].N || p.K != ps[0].K) return -1;
+        const int slot = p.taps == 11 ? 0 : (p.taps == 7 ? 1 : (p.taps == 3 ? 2 : -1));
+        if (slot < 0 || order[slot] >= 0) return -1;
+        order[slot] = i;
+    }
+    const int e = mx_epi_variant(ps[0]);
+    if (e != mx_epi_variant(ps[1]) || e != mx_epi_variant(ps[2])) return -1;
+    if (e != EPI_MXP && e != (EPI_RESPL | EPI_LEAN | EPI_MXP)) return -1;
+    if (check_only) return 0;
+    ConvGemmGroup3 g;
+    for (int i = 0; i < 3; ++i) g.p[i] = ps[order[i]];
+    const int tiles = (ps[0].M / PH_BM) * (ps[0].N / 128), padded = (tiles + 7) & ~7;
+    g.n0 = padded; g.n01 = 2 * padded;
+    const int grid = 2 * padded + tiles;          // (the last problem needs no padding blocks)
+    if (e == EPI_MXP) hipLaunchKernelGGL((conv_gemm_mx_group3_kernel<EPI_MXP>), dim3(grid), dim3(512), PH_LDS, s, g);
+    else hipLaunchKernelGGL((conv_gemm_mx_group3_kernel<EPI_RESPL | EPI_LEAN | EPI_MXP>), dim3(grid), dim3(512), PH_LDS, s, g);
+    return 0;
 }

@@ -84,6 +84,9 @@ int mx_check(const ConvGemmParams& p);
 // 0 if ConvGemmParams::ksplit is consistent with the rest of the call (<= 1, or a DT_F32S call whose shape and scratch allow the split)
 int splitk_check(const ConvGemmParams& p);
 void launch_conv_gemm(const ConvGemmParams& p, hipStream_t s);
+// Three independent DT_MX convs of the conv_gemm_mx_kernel family (same M, N, K and epilogue form, taps {3, 7, 11}, plane sets in) as ONE grid -- the same-level
+// convs of a generator stage's three ResBlocks; 0 = launched (check_only: would be), -1 = not such a triple (launch them one by one: the results are the same bits)
+int launch_conv_gemm_group3(const ConvGemmParams* ps, hipStream_t s, bool check_only = false);
 // which kernel launch_conv_gemm runs a DT_MX call on: 0 = the split-precision fallback (three fp16 MFMAs per product), 1 = conv_gemm_mx_kernel,
 // 2 = conv_c64_mx_kernel (profiling records name the launch by this, not by what the caller hoped for)
 int mx_launch_kind(const ConvGemmParams& p);

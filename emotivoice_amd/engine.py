@@ -35,7 +35,7 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "mx", keep_stages:
                    token_rate: str = "split", vocoder_chunk_mb: int = 0, vocoder_streams: int = 0,
                    vocoder_precision: str = "mx", mx_residual: str = "planes", decoder_attention: str = "split",
                    fused_pairs: bool = True, mx_mrf: str = "planes", decoder_ln: str = "planes", token_splitk: bool = True,
-                   mx_act_format: str = "e5m2") -> _ffi.ev_config:
+                   mx_act_format: str = "e5m2", mx_group: bool = True) -> _ffi.ev_config:
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
     for f in ("n_vocab", "n_speaker", "n_mels", "hidden", "heads", "enc_layers", "dec_layers", "ffn_kernel", "bert_dim",
@@ -67,6 +67,7 @@ def make_ev_config(shapes: EVShapes, decoder_precision: str = "mx", keep_stages:
     cfg.decoder_ln_planes = {"planes": 0, "fp32": 1}[decoder_ln]     # MX decoder: LayerNorm writes its consumer's plane set / fp32 + a planes pass
     cfg.token_splitk = 0 if token_splitk else 1                       # the token-rate conv-FFN's second conv split-K (shape rule) / one pass
     cfg.mx_act_format = {"e5m2": 0, "fp4": 1}[mx_act_format]          # activation operand of the cross terms where a kernel offers both (fused C = 32 pairs)
+    cfg.mx_group = 0 if mx_group else 1                               # same-level convs of a stage's three ResBlocks as one grouped launch / one launch per conv
     return cfg
 
 
@@ -77,14 +78,14 @@ class EVEngine:
                  keep_stages: bool = False, token_rate: str = "split", vocoder_chunk_mb: int = 0,
                  vocoder_streams: int = 0, vocoder_precision: Optional[str] = None, precision: Optional[str] = None,
                  mx_residual: str = "planes", decoder_attention: str = "split", fused_pairs: bool = True, mx_mrf: str = "planes",
-                 decoder_ln: str = "planes", token_splitk: bool = True, mx_act_format: str = "e5m2"):
+                 decoder_ln: str = "planes", token_splitk: bool = True, mx_act_format: str = "e5m2", mx_group: bool = True):
         self.shapes = shapes or EVShapes()
         self._lib = _ffi.lib()
         self._h = C.c_void_p()
         decoder_precision, vocoder_precision = resolve_precision(precision, decoder_precision, vocoder_precision)
         self.decoder_precision, self.vocoder_precision = decoder_precision, vocoder_precision
         cfg = make_ev_config(self.shapes, decoder_precision, keep_stages, token_rate, vocoder_chunk_mb, vocoder_streams,
-                             vocoder_precision, mx_residual, decoder_attention, fused_pairs, mx_mrf, decoder_ln, token_splitk, mx_act_format)
+                             vocoder_precision, mx_residual, decoder_attention, fused_pairs, mx_mrf, decoder_ln, token_splitk, mx_act_format, mx_group)
         if self._lib.ev_create(device_id, C.byref(cfg), C.byref(self._h)) != 0:
             raise EVError(self._lib.ev_last_error(None).decode())
         self.device_id = device_id

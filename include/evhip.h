@@ -30,13 +30,14 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 6      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info;
+#define EV_ABI_VERSION 7      /* 2: ev_config engine switches (mx_residual, decoder_attention, fused_pairs), ev_abi_info;
                                  3: ev_config.mx_mrf / decoder_ln_planes, partial plane sets in ev_conv_gemm_desc (acc_h ..., mxo_partial);
                                  4: ev_config.token_splitk, ev_conv_gemm_desc.ksplit (same struct sizes);
                                  5: ev_default_config() sets decoder_precision = vocoder_precision = EV_PREC_MX, the mode that meets the 1e-3 contract
                                     (same struct sizes; until 4 the default was EV_PREC_F16 = 2.4e-3 on zero-mean audio);
                                  6: ev_config.mx_act_format (was reserved[0], same struct size): the fused C = 32 pairs of the MX generator default to
-                                    E5M2 activation operands in the cross terms -- the results of the default mode change in their last bits */
+                                    E5M2 activation operands in the cross terms -- the results of the default mode change in their last bits;
+                                 7: ev_config.mx_group appended (sizeof(ev_config) + 4): grouped launches of a stage's same-level ResBlock convs -- same bits */
 
 typedef struct ev_handle ev_handle;
 
@@ -110,6 +111,10 @@ typedef struct ev_config {
                                    ResBlock pairs at 32 channels): 0 (default) = OCP E5M2 without block maxima -- Q(xh) = the top byte of the fp16 hi part,
                                    Q(xl) = E5M2 of the remainder at the constant block scale 2^-11; per-element exponents, ~3x fewer quantiser instructions,
                                    emulated waveform error 2 % LOWER than fp4's; 1 = block-scaled fp4 (e2m1) as in ABI <= 5.  Weights are fp4 planes either way. */
+    int32_t mx_group;           /* EV_PREC_MX generator, stages with >= 128 channels, large batches (ABI 7): 0 (default) = the same-level convs of a stage's three
+                                   ResBlocks (k = 3 / 7 / 11: independent until the MRF sum) are issued as ONE grouped launch per level -- a launch of its own
+                                   costs each conv 30-50 us of ramp and tail at B = 32 x 1024 frames -- with one set of intermediates per ResBlock
+                                   (+ ~5 GB of workspace at that size); 1 = one launch per conv, ResBlock after ResBlock.  The same bits either way. */
 } ev_config;
 
 /* Precision of the frame-rate path (ev_default_config: MX for both components).  F16: fp16 MFMA operands (what BASELINE.json's bf16 / fp16 configs name).

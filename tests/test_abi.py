@@ -53,7 +53,7 @@ def test_struct_layouts_match_the_c_headers(tmp_path):
 def test_abi_info_reports_what_the_binding_expects():
     """ev_abi_info is what _ffi.lib() checks at load time: a stale libevhip.so or a stale binding must fail there."""
     sizes = (C.c_size_t * 4)()
-    assert _ffi.lib().ev_abi_info(sizes) == _ffi.EV_ABI_VERSION == 6
+    assert _ffi.lib().ev_abi_info(sizes) == _ffi.EV_ABI_VERSION == 7
     assert tuple(sizes) == (C.sizeof(_ffi.ev_config), C.sizeof(_ffi.ev_result), C.sizeof(_ffi.ev_conv_gemm_desc), C.sizeof(_ffi.ev_res_pair_desc))
     hdr = open(os.path.join(ROOT, "include", "evhip.h")).read()
     assert re.search(r"#define EV_ABI_VERSION\s+%d\b" % _ffi.EV_ABI_VERSION, hdr)
@@ -63,12 +63,12 @@ def test_engine_switches_are_config_fields_not_environment_variables():
     """Round 3's EV_MX_RESPL / EV_ATTN_F32 / EV_NO_FUSED_PAIR became ev_config fields; the product library calls getenv nowhere."""
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
-    assert (cfg.mx_residual, cfg.decoder_attention, cfg.fused_pairs, cfg.mx_mrf, cfg.decoder_ln_planes, cfg.token_splitk, cfg.mx_act_format) == (0, 0, 0, 0, 0, 0, 0)
+    assert (cfg.mx_residual, cfg.decoder_attention, cfg.fused_pairs, cfg.mx_mrf, cfg.decoder_ln_planes, cfg.token_splitk, cfg.mx_act_format, cfg.mx_group) == (0, 0, 0, 0, 0, 0, 0, 0)
     from emotivoice_amd.engine import make_ev_config
     from emotivoice_amd.config import EVShapes
     c2 = make_ev_config(EVShapes(), "mx", vocoder_precision="mx", mx_residual="fp32", decoder_attention="f32", fused_pairs=False, mx_mrf="fp32",
-                        decoder_ln="fp32", token_splitk=False, mx_act_format="fp4")
-    assert (c2.mx_residual, c2.decoder_attention, c2.fused_pairs, c2.mx_mrf, c2.decoder_ln_planes, c2.token_splitk, c2.mx_act_format) == (1, 1, 1, 1, 1, 1, 1)
+                        decoder_ln="fp32", token_splitk=False, mx_act_format="fp4", mx_group=False)
+    assert (c2.mx_residual, c2.decoder_attention, c2.fused_pairs, c2.mx_mrf, c2.decoder_ln_planes, c2.token_splitk, c2.mx_act_format, c2.mx_group) == (1, 1, 1, 1, 1, 1, 1, 1)
     with pytest.raises(KeyError):
         make_ev_config(EVShapes(), mx_residual="bf16")
     out = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True).stdout
@@ -89,7 +89,7 @@ def test_default_config_is_the_contract_precision():
     fp16 operands (2.4e-3 on zero-mean audio) are an explicit opt-in everywhere."""
     cfg = _ffi.ev_config()
     _ffi.lib().ev_default_config(C.byref(cfg))
-    assert (cfg.abi_version, cfg.decoder_precision, cfg.vocoder_precision) == (6, _ffi.EV_PREC_MX, _ffi.EV_PREC_MX)
+    assert (cfg.abi_version, cfg.decoder_precision, cfg.vocoder_precision) == (7, _ffi.EV_PREC_MX, _ffi.EV_PREC_MX)
     from emotivoice_amd.config import EVShapes
     from emotivoice_amd.engine import make_ev_config
     from emotivoice_amd.generator import DEFAULT_PRECISION
@@ -153,7 +153,7 @@ def test_ev_create_rejects_shapes_the_kernels_do_not_build():
                        (dict(vocoder_precision=1), "vocoder_precision"), (dict(decoder_precision=7), "decoder_precision"),
                        (dict(n_rb=5), "generator layout"), (dict(abi_version=99), "abi_version"), (dict(abi_version=1), "abi_version"),
                        (dict(mx_residual=2), "mx_residual"), (dict(mx_mrf=3), "mx_mrf"), (dict(abi_version=2), "abi_version"), (dict(abi_version=3), "abi_version"),
-                       (dict(token_splitk=2), "token_splitk"), (dict(mx_act_format=2), "mx_act_format")):
+                       (dict(token_splitk=2), "token_splitk"), (dict(mx_act_format=2), "mx_act_format"), (dict(mx_group=2), "mx_group")):
         rc, msg = create(**kw)
         assert rc != 0 and needle in msg, (kw, msg)
 

@@ -95,8 +95,9 @@ def test_profiling_counters_and_errors(ctx):
     eng.set_profiling(False)
     assert t["total"] > 0 and t["vocoder"] > 0 and t["am"] > 0 and t["total"] >= t["vocoder"]
     # the handle is the ABI's own default = the contract mode (mx): conv_pre on the split-precision kernel; 3 up-convs + the 36 ResBlock convs of
-    # stages 0-1 on the MX conv-GEMM; stage 2: the last up-conv + 12 layer-wise k = 7 / 11 convs + 3 fused k = 3 pairs; stage 3: 9 fused pairs
-    assert ks["voc_conv_gemm_x3"]["launches"] == 1 and ks["voc_conv_gemm_mx"]["launches"] == 39
+    # stages 0-1 on the MX conv-GEMM -- per stage five grouped launches of three convs each + the ResBlocks' three last convs (round 6: ev_config.mx_group) --;
+    # stage 2: the last up-conv + 12 layer-wise k = 7 / 11 convs + 3 fused k = 3 pairs; stage 3: 9 fused pairs
+    assert ks["voc_conv_gemm_x3"]["launches"] == 1 and ks["voc_conv_gemm_mx"]["launches"] == 3 + 2 * (5 + 3)
     assert ks["voc_conv_c64_mx"]["launches"] == 13 and ks["voc_resblock_pair_c64_mx"]["launches"] == 3
     assert ks["voc_resblock_pair_c32_mx"]["launches"] == 9
     assert ks["voc_conv_gemm_mx"]["flops"] > 0 and ks["dec_f32_attention"]["launches"] == 4 and ks["dec_mx_gemm"]["launches"] == 16
@@ -181,4 +182,33 @@ def test_small_batch_three_stream_generator_equals_single_stream_bitwise(ctx):
     first = ctx["eng"].synthesize(ctx["utts"][:1])["wav"].copy()
     for _ in range(5):
         assert np.array_equal(ctx["eng"].synthesize(ctx["utts"][:1])["wav"], first)
+    one.close()
+
+
+def test_grouped_level_launches_equal_one_launch_per_conv_bitwise(ctx):
+    """Round 6 (ev_config.mx_group): above the small-batch threshold the conv_gemm_mx_kernel stages of the default generator issue the three ResBlocks' same-level
+    convs as ONE grouped grid (conv_gemm_mx_group3_kernel: the k = 11 tiles, then the k = 7 tiles, then the k = 3 tiles, each running its own instantiation's code
+    on its own problem, one set of intermediates per ResBlock); mx_group = False issues one launch per conv, ResBlock after ResBlock.  Same products in the same order:
+    bit-identical waveforms -- and the grouped path must really be taken: its launches appear in the profile as voc_conv_gemm_mx records whose taps are 3 + 7 + 11."""
+    from emotivoice_amd.engine import EVEngine
+    from emotivoice_amd.synthetic import synth_inputs
+    one = EVEngine(mx_group=False)
+    one.load_blob(ctx["blob"], ctx["man"])
+    utts = synth_inputs(84, [200, 180, 190, 170, 60], [5, 6, 7, 8, 9])          # > 2048 frame rows: the large-batch path
+    a = ctx["eng"].synthesize(utts)
+    b = one.synthesize(utts)
+    assert int(sum(a["mel_lens"])) > 2048
+    assert np.array_equal(a["durations"], b["durations"]) and np.array_equal(a["mel"], b["mel"])
+    assert np.array_equal(a["wav"], b["wav"])
+    for _ in range(3):          # run to run
+        assert np.array_equal(ctx["eng"].synthesize(utts)["wav"], a["wav"])
+    ctx["eng"].set_profiling(True)
+    try:
+        c = ctx["eng"].synthesize(utts)
+        recs = ctx["eng"].launch_records()
+    finally:
+        ctx["eng"].set_profiling(False)
+    assert np.array_equal(c["wav"], a["wav"])
+    grouped = [r for r in recs if r["name"] == "voc_conv_gemm_mx" and r["taps"] == 21]
+    assert len(grouped) == 10, len(grouped)          # stages 0 and 1: five grouped levels each
     one.close()

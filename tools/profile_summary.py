@@ -44,6 +44,10 @@ def _is_f16_gemm(name):
     return "conv_gemm_kernelIDF16" in name or "conv_gemm_phased_kernel" in name
 
 
+def _is_mx_gemm(name):
+    return "conv_gemm_mx_kernel" in name or "conv_gemm_mx_group3_kernel" in name
+
+
 FAMILIES = {
     # (the fp16 family = the 4-wave kernel + the phased 8-wave kernel that takes its MFMA-bound shapes)
     "conv_gemm_f16_vocoder": lambda f: [r for r in f if _is_f16_gemm(r["Kernel_Name"])][N_DEC:],
@@ -53,8 +57,9 @@ FAMILIES = {
     "conv_gemm_split_token_rate": lambda f: [r for r in f if "conv_gemm_split_kernel" in r["Kernel_Name"] or "conv_gemm_x3_kernel" in r["Kernel_Name"]],
     "layernorm": lambda f: [r for r in f if "layernorm_kernel" in r["Kernel_Name"]],
     # round 3, "mx" precision (bench.py's default): the generator's three MX kernels, the decoder's conv-FFN on the same conv-GEMM kernel
-    "conv_gemm_mx_vocoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][N_DEC_MX:],
-    "conv_gemm_mx_decoder": lambda f: [r for r in f if "conv_gemm_mx_kernel" in r["Kernel_Name"]][:N_DEC_MX],
+    # (round 6: the same-level convs of a stage's three ResBlocks are ONE grouped launch of conv_gemm_mx_group3_kernel -- the family has 19 launches instead of 39)
+    "conv_gemm_mx_vocoder": lambda f: [r for r in f if _is_mx_gemm(r["Kernel_Name"])][N_DEC_MX:],
+    "conv_gemm_mx_decoder": lambda f: [r for r in f if _is_mx_gemm(r["Kernel_Name"])][:N_DEC_MX],
     # (round 4: the two-group variants conv_c64_mx2_kernel / resblock_pair_c32_mx2_kernel are the launchers' default; the fused C = 64 / k = 3 pair)
     # (round 4, second half: the k = 7 / 11 launches of stage 2 run on the streamed conv_gemm_mx64_kernel, the k = 3 up-conv on the persistent conv_c64_mx kernels)
     "conv_c64_mx": lambda f: [r for r in f if "conv_c64_mx" in r["Kernel_Name"] or "conv_gemm_mx64_kernel" in r["Kernel_Name"]],
