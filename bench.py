@@ -647,7 +647,6 @@ def main():
         torch.cuda.synchronize()
 
     frames, dt = timed(work, args.steps, args.warmup, sync)
-    power = power_sample(work, torch) if (rank == 0 and world == 1) else None
     ranks_seen = [0]
     per_rank = [dict(rank=0, frames=int(frames), s=round(dt, 6))]
     if dist is not None:
@@ -660,9 +659,11 @@ def main():
         frames = sum(r["frames"] for r in per_rank)
         dt = max(r["s"] for r in per_rank)
 
-    roof, stages, kernels, lat, other = None, {}, {}, lat0, None
+    roof, stages, kernels, lat, other, power = None, {}, {}, lat0, None, None
     if rank == 0:
         roof, stages, kernels = roofline_block(eng, work, torch, args.dump_launches)
+        # (behind the profiled step: 2.5 s of sustained load in front of it cost its per-launch numbers 5-10 % -- the chip throttles further as it warms)
+        power = power_sample(work, torch) if world == 1 else None
         # the same workload in the other precisions (one engine at a time: the previous one's workspace is released first)
         if world == 1 and not args.no_other_precision and args.decoder_precision is None:
             eng.close()
