@@ -69,7 +69,7 @@ class ev_conv_gemm_desc(C.Structure):
         ("out32_before_post", C.c_int), ("reserved0", C.c_int),
         ("add16_a", C.c_void_p), ("add16_b", C.c_void_p), ("ldadd", C.c_int), ("ksplit", C.c_int),
         ("W_mx", C.c_void_p), ("mx_scratch", C.c_void_p), ("mx_scratch_size", C.c_size_t),
-        ("mx_x4", C.c_void_p * 2), ("mx_xs", C.c_void_p * 2), ("mx_xs_stride", C.c_uint), ("reserved2", C.c_int),
+        ("mx_x4", C.c_void_p * 2), ("mx_xs", C.c_void_p * 2), ("mx_xs_stride", C.c_uint), ("polyphase_cout", C.c_int),
         ("mxo_h", C.c_void_p), ("mxo_q4", C.c_void_p * 2), ("mxo_qs", C.c_void_p * 2), ("mxo_qs_stride", C.c_uint),
         ("mxo_logC", C.c_int), ("mxo_slope", C.c_float), ("reserved3", C.c_int),
         ("res_x4", C.c_void_p), ("res_xs", C.c_void_p), ("res_xs_stride", C.c_uint), ("res_inv_slope", C.c_float),

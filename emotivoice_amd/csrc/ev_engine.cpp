@@ -620,6 +620,7 @@ int run_vocoder(ev_handle* h, const Buf& melin, int Rf, double n_frames, VocBufs
         p = gemm_defaults();
         if (voc_weights(h, "voc.up" + std::to_string(i), x3, p, mx)) return -1;
         p.A = prev; p.lda = ch; p.M = rows_in; p.N = s * cout; p.K = ch; p.taps = 3; p.center = 1;
+        if (cout % 64 == 0 && s % 2 == 0) p.polyphase_cout = cout;          // (conv_gemm_mx_kernel skips the zero tap of each output phase; other kernels ignore the hint)
         p.row_valid = h->d_frm_valid; p.valid_shift = ilog2(U); p.ldo = s * cout;
         if (x3) { p.pro_lrelu = 1; p.pro_slope = 0.1f; }          // models.py:118 (the fp16 path has it in the producer's epilogue)
         set_out(p, vb.xu[i].p);

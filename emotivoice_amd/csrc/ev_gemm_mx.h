@@ -102,7 +102,10 @@ static constexpr int MX_XS_OFF = 20480, MX_WS_OFF = 22528;
 
 // One 256-row x 128-channel tile of a launch.  bid_in / nblk: the block's index among the launch's (or, in a grouped launch, the problem's) blocks and their
 // number; a grouped launch pads every problem to a multiple of eight blocks so that bid_in & 7 is the XCD the hardware's round-robin gave the block.
-template <int TAPS, int EPI>
+// ZT (TAPS == 3 only): the tap whose weights are all zero for this WAVE's 64 output channels -- a transposed conv in polyphase form, conv_gemm_mx_up_kernel -- or -1.
+// Its steps keep their requests, waits and barriers and issue no fragment reads and no matrix instructions.  A compile-time parameter: with a run-time test around
+// the MFMA block hipcc gave the accumulators different registers on the two paths (430-490 spilled registers in every k = 3 instantiation).
+template <int TAPS, int EPI, int ZT = -1>
 __device__ __forceinline__ void conv_gemm_mx_tile(const ConvGemmParams& p, const int bid_in, const int nblk) {
     constexpr int BM = PH_BM, XBUF = PH_XBUF, WBUF = PH_WBUF, U = TAPS, TC = 64, MT = 4, NT = 4;
     static_assert(U >= 3 && TAPS * 128 <= 2048 && PH_SLABR >= BM + MAX_SPAN + 64, "pipeline depth / scale pieces");
@@ -137,6 +140,7 @@ __device__ __forceinline__ void conv_gemm_mx_tile(const ConvGemmParams& p, const
     }
     if (bid >= (p.M / BM) * nN) return;          // (padding blocks of a grouped launch; never true for a launch of its own)
     const int m0 = (bid / nN) * BM, nt = bid % nN, n0 = nt * 128;
+
     const int nkc16_ = p.K >> 5, nkc4 = p.K >> 7;
     const unsigned K2 = (unsigned)p.K >> 1;                // row / tap pitch of a fp4 plane in bytes; the fp16 planes' is 4 x that
     const unsigned wrp4 = K2 * TAPS;
@@ -246,7 +250,7 @@ __device__ __forceinline__ void conv_gemm_mx_tile(const ConvGemmParams& p, const
         (void)in_cur;                                                                                                   \
         uint4 xf[MT], wf[NT];                                                                                           \
         int xsc[MT], wsc[NT];                                                                                           \
-        {                                                                                                               \
+        if (ZT != (u)) {                                                                                      \
             const int row0_ = wt * 64 + fr + (u) * dil_;                                                                \
             const char* xp = Xb + row0_ * 64 + ((fq ^ ((row0_ >> 1) & 3)) << 4);                                        \
             const char* wp = Ws + (s & 3) * WBUF + woff;                                                                \
@@ -262,6 +266,14 @@ __device__ __forceinline__ void conv_gemm_mx_tile(const ConvGemmParams& p, const
         __builtin_amdgcn_s_barrier();                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
+        if (ZT == (u)) {          /* polyphase transposed conv: this tap's weights are zeros -- requests only */ \
+            EV_MX_ISSUE_W(wsel, wsh, u3, (s + 3) & 3)                                                                   \
+            if ((u) == 0 && more) {                                                                                     \
+                EV_MX_ISSUE_X(nxb, nsc, nsh, nmx, (q + 1) & 1, 0)                                                       \
+                EV_MX_ISSUE_X(nxb, nsc, nsh, nmx, (q + 1) & 1, 1)                                                       \
+                EV_MX_ISSUE_X(nxb, nsc, nsh, nmx, (q + 1) & 1, 2)                                                       \
+            }                                                                                                           \
+        } else {                                                                                                        \
         _Pragma("unroll") for (int a = 0; a < NT; ++a) {                                                                \
             _Pragma("unroll") for (int b = 0; b < MT; ++b) {                                                            \
                 if constexpr (MX) mfma_mx_inplace(acc[a][b], wf[a], xf[b], wsc[a], xsc[b]);                             \
@@ -274,6 +286,7 @@ __device__ __forceinline__ void conv_gemm_mx_tile(const ConvGemmParams& p, const
                     if (idx == 6) { EV_MX_ISSUE_X(nxb, nsc, nsh, nmx, (q + 1) & 1, 2) }                                 \
                 }                                                                                                       \
             }                                                                                                           \
+        }                                                                                                               \
         }                                                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
@@ -381,6 +394,24 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_mx_kernel(const ConvGemmPara
     conv_gemm_mx_tile<TAPS, EPI>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// ConvTranspose1d(k = 2 s, stride s, pad s / 2) as a 3-tap conv with N = s * C_out (packer._convT_to_gemm; ConvGemmParams::polyphase_cout = C_out): output phases below
+// s / 2 have no weights in tap 2, the others none in tap 0.  A wave's 64 output channels lie inside one phase, so each WAVE runs the instantiation that skips its zero
+// tap (same requests, waits and barriers in both: the block's waves stay in step) -- a third of the launch's matrix instructions and fragment reads are not issued.
+// The remaining products and their order are those of the plain launch: the same bits.
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void conv_gemm_mx_up_kernel(const ConvGemmParams p) {
+    const int nblk = (int)gridDim.x, nN = p.N >> 7;
+    int bid = (int)blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;          // (conv_gemm_mx_tile's own remap: the tile this block will take)
+    }
+    const int wc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int phase = ((bid % nN) * 128 + wc * 64) / p.polyphase_cout, half_s = (p.N / p.polyphase_cout) >> 1;
+    if (phase < half_s) conv_gemm_mx_tile<3, EPI, 2>(p, (int)blockIdx.x, nblk);
+    else conv_gemm_mx_tile<3, EPI, 0>(p, (int)blockIdx.x, nblk);
+}
+
 // Grouped launch (round 6): the same-level convs of a stage's three ResBlocks (k = 11, 7, 3; same M, N, K, same epilogue form) are independent, and a launch of its
 // own costs each of them 30-50 us of ramp + tail (tools/bench_mxgemm.py: 2 x T(M / 2) - T(M)).  One grid carries the three problems' tiles back to back, longest
 // tiles first: a CU that runs out of k = 11 tiles continues with k = 7 tiles, and the launch ends on the short k = 3 tiles.  Every tile runs the code of its own
@@ -457,6 +488,14 @@ static int mx_epi_variant(const ConvGemmParams& p) {
 #endif
 template <int TAPS>
 static void launch_mx_taps(const ConvGemmParams& p, int e, hipStream_t s) {
+    if constexpr (TAPS == 3) {
+        if (p.polyphase_cout > 0 && (e == EPI_MXP || e == (EPI_O32 | EPI_MXP))) {
+            const int grid = (p.M / PH_BM) * (p.N / 128);
+            if (e == EPI_MXP) hipLaunchKernelGGL((conv_gemm_mx_up_kernel<EPI_MXP>), dim3(grid), dim3(512), PH_LDS, s, p);
+            else hipLaunchKernelGGL((conv_gemm_mx_up_kernel<EPI_O32 | EPI_MXP>), dim3(grid), dim3(512), PH_LDS, s, p);
+            return;
+        }
+    }
 #ifdef EV_MX_NOLEAN
     if ((p.reserved0 & 2) && (e & EPI_RESPL) && (e & EPI_MXP) && !(e & (EPI_O32 | EPI_ACC32))) e &= ~EPI_LEAN;
 #endif
@@ -481,6 +520,8 @@ static hipError_t mx_set_attributes() {
     r = mx_attr_taps<7>(); if (r != hipSuccess) e = r;
     r = mx_attr_taps<11>(); if (r != hipSuccess) e = r;
     r = mx1_set_attributes(); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_mx_up_kernel<EPI_MXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
+    r = hipFuncSetAttribute((const void*)conv_gemm_mx_up_kernel<EPI_O32 | EPI_MXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
     r = hipFuncSetAttribute((const void*)conv_gemm_mx_group3_kernel<EPI_MXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
     r = hipFuncSetAttribute((const void*)conv_gemm_mx_group3_kernel<EPI_RESPL | EPI_LEAN | EPI_MXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PH_LDS); if (r != hipSuccess) e = r;
     return e;
@@ -490,6 +531,8 @@ static hipError_t mx_set_attributes() {
 // and inside a batch.  Everything else of a DT_MX call runs as the split-precision (three fp16 MFMAs) kernel.
 static bool mx_shape_ok(const ConvGemmParams& p) {
     if (p.taps == 1) return mx1_shape_ok(p);          // nn.Linear: the one-tap pipeline (ev_gemm_mx1.h)
+    // (polyphase hint: a wave's 64 output channels must lie inside one phase, and the phases split evenly into the two tap pairs)
+    if (p.polyphase_cout && (p.taps != 3 || p.polyphase_cout < 0 || p.polyphase_cout % 64 || p.N % p.polyphase_cout || ((p.N / p.polyphase_cout) & 1))) return false;
     return p.W_mx && p.N % 128 == 0 && p.K % 128 == 0 && (p.taps == 3 || p.taps == 7 || p.taps == 11) && p.M % PH_BM == 0 &&
            p.lda == p.K && (p.taps - 1) * p.dil <= MAX_SPAN;
 }

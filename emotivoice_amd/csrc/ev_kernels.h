@@ -56,8 +56,11 @@ struct ConvGemmParams {
     // Activations, either (a) A = fp32 [M][K] + mx_scratch (>= mx_scratch_bytes(M, K) bytes): the launcher first runs mx_planes_kernel
     // (leaky-relu of pro_lrelu, then the planes) into the scratch, or (b) a plane set written by the producer's epilogue (mxo below):
     // A = the fp16 hi plane (lda == K), mx_x4 / mx_xs / mx_xs_stride = its code and scale planes; pro_lrelu must be 0.
+    // polyphase_cout > 0 (DT_MX, taps == 3, conv_gemm_mx_kernel launches): the call is a ConvTranspose1d(k = 2 s, stride s, pad s / 2) run as a 3-tap conv with
+    // N = s * polyphase_cout (packer._convT_to_gemm): output phase n / polyphase_cout < s / 2 has an all-zero tap 2, the other phases an all-zero tap 0, and the kernel
+    // skips that tap's matrix instructions (a third of the launch's).  0: every tap is multiplied.  The weights' zero tap must really be zero.
     const void* W_mx; void* mx_scratch; size_t mx_scratch_size;
-    const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int reserved2;
+    const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int polyphase_cout;
     // Plane-set OUTPUT (any dtype whose launch takes an EPI_MXP epilogue: DT_MX kernels): besides / instead of out32 the epilogue writes
     // the planes of a = lrelu(result, mxo_slope) (slope 1 = none) viewed as [rows][C], C = 2^mxo_logC, or C = N when mxo_logC == 0
     // (ldo == N; a transposed conv's [M][s * C] output is the [M * s][C] tensor): mxo_h fp16(a); mxo_q4[0] / [1] fp4 codes of fp16(a) and of a - fp16(a), C / 2 bytes

@@ -47,8 +47,11 @@ typedef struct ev_conv_gemm_desc {
                                                  // ksplit <= 1, so a caller that promises batch invariance picks it by layer shape, never by M.
     const void* W_mx;          /* dtype 3: emotivoice_amd/mxfp4.py pack_weight_planes(W) on the device (NULL: the call runs as dtype 2) */
     void* mx_scratch; size_t mx_scratch_size;   /* dtype 3 with fp32 A: device scratch, >= ev_op_mx_scratch_bytes(M, K) */
-    const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int reserved2;   /* dtype 3 with a plane-set input: A = its fp16 hi
-                                  plane, these = its fp4 code planes (hi, lo), E8M0 scale planes and the chunk stride of those; else zero */
+    const void* mx_x4[2]; const void* mx_xs[2]; unsigned mx_xs_stride; int polyphase_cout;   /* dtype 3 with a plane-set input: A = its fp16 hi
+                                  plane, these = its fp4 code planes (hi, lo), E8M0 scale planes and the chunk stride of those; else zero.
+                                  polyphase_cout > 0 (dtype 3, taps 3): the call is a ConvTranspose1d(k = 2 s, stride s, pad s / 2) as a 3-tap conv with
+                                  N = s * polyphase_cout (packer._convT_to_gemm): phases below s / 2 have an all-zero tap 2, the others an all-zero tap 0,
+                                  and the MX conv-GEMM skips that tap's matrix instructions; 0 = every tap is multiplied */
     /* plane-set output (dtype 3): planes of lrelu(result, mxo_slope) as [rows][2^mxo_logC]: fp16 hi plane, fp4 code planes of the hi / lo
        parts, their scale planes [C/128][mxo_qs_stride/4][4]; all NULL = none.  emotivoice_amd/mxfp4.py states the contents. */
     void* mxo_h; void* mxo_q4[2]; void* mxo_qs[2]; unsigned mxo_qs_stride; int mxo_logC; float mxo_slope; int reserved3;

@@ -786,6 +786,55 @@ def test_mx_conv_gemm_fp32_input(lib, Cc, N, k, dil, M):
     assert _rel(emu, exact) > 1e-6          # (the test would be vacuous if the emulation were exact)
 
 
+@pytest.mark.parametrize("cin,s", [(512, 8), (256, 8), (128, 2)])
+def test_mx_transposed_conv_skips_its_zero_tap_bitwise(lib, cin, s):
+    """The generator's up-convs on conv_gemm_mx_kernel (ConvTranspose1d(k = 2 s, stride s, pad s / 2) as a 3-tap conv, packer._convT_to_gemm): every output phase has
+    one all-zero tap.  With ev_conv_gemm_desc.polyphase_cout the kernel issues no matrix instruction for it (round 6: a third of the launch's); the products that are
+    left and their order are the same, so outputs and plane sets must equal the launch that multiplies the zeros -- and the torch ConvTranspose1d to the MX level."""
+    from emotivoice_amd import _ffi
+    from emotivoice_amd.packer import _convT_to_gemm
+    torch.manual_seed(77 + cin + s)
+    cout, M = cin // 2, 256 * 3
+    N = s * cout
+    full = torch.randn(M + 2 * PAD, cin, device="cuda") * torch.exp(0.5 * torch.randn(M + 2 * PAD, 1, device="cuda"))
+    full[:PAD] = 0
+    full[PAD + M:] = 0
+    x = full[PAD:PAD + M]
+    wt = torch.randn(cin, cout, 2 * s) / math.sqrt(cin * 2)
+    wg = torch.from_numpy(_convT_to_gemm(wt.numpy(), s))              # [s * cout][3][cin]
+    wts = _mx_weights(wg.permute(0, 2, 1).contiguous().cuda())
+    bias = (torch.randn(cout) * 0.1).repeat(s).cuda()
+    valid = torch.ones(M // 4, dtype=torch.uint8, device="cuda")
+    valid[:3] = 0
+    nb = lib.ev_op_mx_scratch_bytes(M, cin)
+    outs = []
+    for hint in (0, cout):
+        d = _mx_desc(lib, wts, M, N, cin, 3, 1, bias)
+        d.A, d.lda = x.data_ptr(), cin
+        d.pro_lrelu, d.pro_slope = 1, 0.1
+        d.row_valid, d.valid_shift = valid.data_ptr(), 2
+        scratch = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        d.mx_scratch, d.mx_scratch_size = scratch.data_ptr(), nb
+        out = torch.full((M, N), 7.0, device="cuda")
+        ps = _PlaneSet(M * s, cout)
+        d.out32 = out.data_ptr()
+        ps.out_fields(d, 0.1)
+        d.polyphase_cout = hint
+        _launch(lib, d)
+        outs.append((out, ps))
+    (o0, p0), (o1, p1) = outs
+    assert torch.equal(o0, o1)
+    assert torch.equal(p0.h, p1.h) and all(torch.equal(p0.q4[i], p1.q4[i]) and torch.equal(p0.qs[i], p1.qs[i]) for i in range(2))
+    ref = F.conv_transpose1d(_lrelu(x.float().cpu(), 0.1).t().unsqueeze(0), wt, bias[:cout].cpu(), stride=s, padding=s // 2).squeeze(0).t()
+    got = o1.cpu().reshape(M * s, cout)
+    vrow = valid.bool().repeat_interleave(4 * s).cpu()
+    assert float(got[~vrow].abs().max()) == 0.0
+    assert _rel(got[vrow], ref[vrow]) < 2e-4
+    # a hint that does not describe whole waves / an even phase count is refused
+    d.polyphase_cout = 32
+    assert lib.ev_op_conv_gemm(C.byref(d), None) != 0
+
+
 @pytest.mark.parametrize("K,N,M,res", [(384, 1152, 256 * 5, False), (384, 384, 256 * 3, True), (128, 128, 256 * 2, False), (1536, 384, 256 * 2, True)])
 def test_mx_one_tap_gemm(lib, K, N, M, res):
     """gemm_mx1_kernel (ev_gemm_mx1.h): nn.Linear in the MX arithmetic (the mel decoder's QKV / output projections): fp32 activation ->

@@ -45,7 +45,7 @@ def _is_f16_gemm(name):
 
 
 def _is_mx_gemm(name):
-    return "conv_gemm_mx_kernel" in name or "conv_gemm_mx_group3_kernel" in name
+    return "conv_gemm_mx_kernel" in name or "conv_gemm_mx_group3_kernel" in name or "conv_gemm_mx_up_kernel" in name
 
 
 FAMILIES = {
